@@ -1,0 +1,446 @@
+"""CPU ORACLE for the HeatAlertEnv reset/step hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain NumPy / pure-Python restatement of the reference algorithm
+(`/root/reference/src/weather2alert/env.py:107-262`, `datautils.py:103-126`). It exists so
+that tests, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg can CHECK the HIP
+path; nothing under `weather2alert_amd/` may import it and the product never falls back
+to it.
+
+Parity pin: the reference has no tests or golden vectors of its own, so this
+oracle is pinned by vectors captured from the unmodified reference env run in the build
+container (`tests/golden/make_golden.py` -> `tests/golden/*.npz`): `tests/test_oracle_golden.py`
+requires integer state bit-exact and float64 rewards/observations bit-exact against them.
+
+Layout of the restatement (each function cites what it follows):
+
+  RefData.from_files     env.py:39-85,104-105   table/weight loading (pandas, like the reference)
+  similar_counties       datautils.py:103-126   climate-zone augmentation set
+  OracleEnv.reset        env.py:133-184, 107-131
+  OracleEnv._get_obs     env.py:186-195
+  OracleEnv._get_reward  env.py:197-226
+  OracleEnv.step         env.py:238-262
+  VectorOracle           the same step arithmetic vectorised over envs (float64, same
+                         summation order), used for large-N checks and the CPU baseline
+  devrng_*               restatement of the build's own counter-based device RNG
+                         (weather2alert_amd/csrc/w2a_kernels.hip: w2a_mix64 / draw slots);
+                         this part has no reference counterpart
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+from scipy.special import expit as _expit  # the reference's sigmoid (env.py:12)
+
+WESTERN_STATE_FIPS = {  # datautils.py:3-17 via FIPS2STATE (:42-100): AZ CA CO ID MT NM NV OR WA ND SD NE KS
+    "03", "04", "06", "08", "16", "30", "35", "32", "41", "53", "38", "46", "31", "20",
+}
+_KNOWN_STATE_PREFIXES = {
+    "01", "02", "03", "04", "05", "06", "08", "09", "10", "11", "12", "13", "15", "16", "17", "18", "19", "20",
+    "21", "22", "23", "24", "25", "26", "27", "28", "29", "30", "31", "32", "33", "34", "35", "36", "37", "38",
+    "39", "40", "41", "42", "44", "45", "46", "47", "48", "49", "50", "51", "53", "54", "55", "56", "72", "60",
+    "66", "69", "78",
+}
+
+
+def similar_counties(fips: str, conf_fips: list[str], conf_zone: list[str]) -> list[str]:
+    """datautils.py:103-126. Counties of a WESTERN_STATES state are all 'Cold-West' whatever
+    their zone (:113-117); other 'Cold' ones become 'Cold-East'; result keeps the confounders'
+    row order (:124)."""
+
+    def zone_of(f, z):
+        if f[:2] in WESTERN_STATE_FIPS:
+            return "Cold-West"
+        return "Cold-East" if z == "Cold" else z
+
+    zones = [zone_of(f, z) for f, z in zip(conf_fips, conf_zone)]
+    mine = zones[conf_fips.index(fips)]  # confounders.loc[fips] -> KeyError/ValueError if absent
+    return [f for f, z in zip(conf_fips, zones) if z == mine]
+
+
+class RefData:
+    """Everything `HeatAlertEnv.__init__` holds (env.py:39-105), as plain arrays."""
+
+    def __init__(self):
+        self.columns: list[str] = []  # the 28 episode columns (21 exo + 7 endo), env.py:128-130
+        self.episodes: dict[tuple[str, int], np.ndarray] = {}  # (fips, year) -> f64 [n_days, 28]
+        self.fips_list: list[str] = []
+        self.valid_years: list[int] = []
+        self.n_samples = 0
+        self.baseline_keys: list[str] = []
+        self.effectiveness_keys: list[str] = []
+        self.wb = None  # f32 [K, n_samples, S] rows in baseline_keys order
+        self.we = None
+        self.conf_fips: list[str] = []
+        self.conf_zone: list[str] = []
+        self.sig_categories: list[str] = []
+
+    # ---- loading from the reference's on-disk format ---------------------------------
+    @classmethod
+    def from_files(cls, data_dir: str, weights: str = "nn_full_medicare_all", split: str = "65k",
+                   years: list | None = None) -> "RefData":
+        import pandas as pd
+        import yaml
+        from safetensors import safe_open
+
+        self = cls()
+        ddir = os.path.join(data_dir, "data", split)
+        merged = pd.merge(  # env.py:49-53
+            pd.read_parquet(os.path.join(ddir, "exogenous_states.parquet")),
+            pd.read_parquet(os.path.join(ddir, "endogenous_states_actions.parquet")),
+            on=["fips", "date"],
+        )
+        merged["year"] = merged.date.str[:4].astype(int)  # env.py:54
+        conf = pd.read_parquet(os.path.join(ddir, "confounders.parquet"))  # env.py:57
+        self.conf_fips = [str(x) for x in conf["fips"].tolist()]
+        self.conf_zone = [str(x) for x in conf["ba_zone"].tolist()]
+        self.columns = [c for c in merged.columns if c not in ("fips", "date", "year")]
+        cats = sorted(x for x in merged["significance"].dropna().unique()) if "significance" in merged else []
+        self.sig_categories = list(cats)
+        num = merged[self.columns].copy()
+        if "significance" in num:
+            num["significance"] = merged["significance"].map(lambda v: 0.0 if v is None or v != v
+                                                             else float(cats.index(v) + 1))
+        vals = num.astype(np.float64).values
+        fy = list(zip(merged["fips"].tolist(), merged["year"].tolist()))
+        # rows of one (fips, year) in file order, like merged.loc[(location, year)] (env.py:127)
+        groups: dict[tuple[str, int], list[int]] = {}
+        for i, k in enumerate(fy):
+            groups.setdefault(k, []).append(i)
+        self.episodes = {k: vals[idx] for k, idx in groups.items()}
+        # env.py:104-105: years in order of first appearance, unless given
+        if years is None:
+            self.valid_years = [int(y) for y in pd.unique(merged["year"])]
+        else:
+            self.valid_years = list(years)
+        post = {}
+        with safe_open(os.path.join(data_dir, weights, "posterior_samples.safetensors"), framework="np") as f:
+            for k in f.keys():  # env.py:69-72 -- dict order = file key order
+                post[k] = f.get_tensor(k)
+        cfg = yaml.safe_load(open(os.path.join(data_dir, weights, "config.yaml")))
+        self.fips_list = [str(x) for x in cfg["fips_list"]]  # env.py:75
+        self._set_weights(post)
+        return self
+
+    def _set_weights(self, post: dict):
+        self.baseline_keys = [k for k in post if k.startswith("baseline")]  # env.py:77-79
+        self.effectiveness_keys = [k for k in post if k.startswith("effectiveness")]  # env.py:80-82
+        self.n_samples = int(post["baseline_bias"].shape[0])  # env.py:85
+        self.wb = np.stack([np.asarray(post[k], np.float32)[:, 0, :] for k in self.baseline_keys])
+        self.we = np.stack([np.asarray(post[k], np.float32)[:, 0, :] for k in self.effectiveness_keys])
+
+    @classmethod
+    def from_synth(cls, d, sorted_keys: bool = True) -> "RefData":
+        """Same content from a dense synthetic data set (duck-typed: weather2alert_amd.synth.SynthData),
+        without the parquet round trip. Column order = exogenous then endogenous file order."""
+        self = cls()
+        exo_cols, endo_cols = d.meta["exo_cols"], d.meta["endo_cols"]
+        self.columns = list(exo_cols) + list(endo_cols)
+        endo = np.stack([np.asarray(getattr(d, c), np.float64) for c in endo_cols], axis=-1)
+        full = np.concatenate([d.exo.astype(np.float64), endo], axis=-1)
+        for ci, f in enumerate(d.fips_weather):
+            for yi, y in enumerate(d.years):
+                self.episodes[(f, int(y))] = full[ci, yi]
+        self.valid_years = [int(y) for y in d.years]
+        self.fips_list = list(d.fips_list)
+        self.conf_fips, self.conf_zone = list(d.confounder_fips), list(d.confounder_zone)
+        self.sig_categories = list(d.meta.get("sig_categories", []))
+        keys = sorted(d.weights) if sorted_keys else list(d.weights)  # safetensors lists keys sorted
+        self._set_weights({k: d.weights[k] for k in keys})
+        return self
+
+    # feature position of each coefficient key inside an episode row (+ 'bias')
+    def key_columns(self, keys: list[str], prefix: str) -> list[int]:
+        out = []
+        for k in keys:
+            name = k.replace(prefix, "")  # env.py:208,215
+            out.append(-1 if name == "bias" else self.columns.index(name))
+        return out
+
+
+class OracleEnv:
+    """Scalar restatement of HeatAlertEnv; attribute names follow the reference."""
+
+    def __init__(self, data: RefData, similar_climate_counties: bool = False, budget: int | None = None):
+        self.d = data
+        self.similar_climate_counties = similar_climate_counties
+        self.budget = budget  # env.py:34 (sticky once set, :167-170)
+        self.fips_list = data.fips_list
+        self.valid_years = data.valid_years
+        self.n_samples = data.n_samples
+        self._bcols = data.key_columns(data.baseline_keys, "baseline_")
+        self._ecols = data.key_columns(data.effectiveness_keys, "effectiveness_")
+        self._i_lag1 = data.columns.index("alert_lag1")
+        self._i_streak = data.columns.index("alert_streak")
+        self._i_rem = data.columns.index("remaining_budget")
+        self._i_hq = data.columns.index("heat_qi")
+        self.feat_names = list(data.columns) + ["alert_2wks"]  # env.py:191 adds a NEW key (Q1)
+
+    # env.py:107-131
+    def _get_episode(self, location: str, augment: bool):
+        if augment:
+            locations = similar_counties(location, self.d.conf_fips, self.d.conf_zone)
+            locations = [x for x in locations if x in self.fips_list]
+            self.location_index = int(self.rng.choice(range(len(locations))))
+            self.location = locations[self.location_index]
+        else:
+            self.location = location
+            self.location_index = self.fips_list.index(location)
+        year = int(self.rng.choice(self.valid_years))
+        return self.d.episodes[(location, year)], year  # weather of the REQUESTED county (Q8)
+
+    # env.py:133-184
+    def reset(self, location=None, similar_climate_counties=None, seed=None, budget=None,
+              sample_budget=False, sample_budget_type="less_than"):
+        if seed is None:
+            seed = np.random.randint(0, 10000)
+        self.rng = np.random.default_rng(seed)
+        if similar_climate_counties is None:
+            similar_climate_counties = self.similar_climate_counties
+        if location is None:
+            location = str(self.rng.choice(self.fips_list))
+        self.ep, year = self._get_episode(location, similar_climate_counties)
+        self.year = year
+        self.ep_index = location + "_" + str(year)
+        self.n_days = self.ep.shape[0]
+        self.coef_index = int(self.rng.integers(0, self.n_samples))
+        self.actual_alert_buffer = []
+        self.attempted_alert_buffer = []
+        self.alert_streak = 0
+        self.t = 0
+        if self.budget is None:
+            self.budget = int(self.ep[0, self._i_rem]) if budget is None else budget
+        if sample_budget:
+            b = self.budget
+            if sample_budget_type == "less_than":
+                self.budget = int(self.rng.integers(0, b + 1))
+            elif sample_budget_type == "centered":
+                self.budget = int(self.rng.integers(0.5 * b, 1.5 * b + 1))
+        self.remaining_budget = self.budget
+        self.at_budget = False
+        self.observation = self._get_obs()
+        return self.observation, self._get_info()
+
+    # env.py:186-195 -> numeric f64 [29]
+    def _get_obs(self):
+        row = np.empty(len(self.d.columns) + 1, np.float64)
+        row[:-1] = self.ep[self.t]
+        row[self._i_lag1] = self.actual_alert_buffer[-1] if self.t > 0 else 0
+        row[-1] = sum(self.actual_alert_buffer[-14:])  # 'alert_2wks' (Q1)
+        row[self._i_streak] = self.alert_streak
+        row[self._i_rem] = self.budget - sum(self.actual_alert_buffer)
+        return row
+
+    # env.py:197-226
+    def _get_reward(self, action):
+        li = self.location_index
+        row = self._get_obs()
+        s = 0  # Python sum() starts from int 0 and adds left to right in key order
+        for j, c in enumerate(self._bcols):
+            x = 1.0 if c < 0 else row[c]
+            s = s + x * float(self.d.wb[j, self.coef_index, li])
+        baseline = _expit(s)
+        s = 0
+        for j, c in enumerate(self._ecols):
+            x = 1.0 if c < 0 else row[c]
+            s = s + x * float(self.d.we[j, self.coef_index, li])
+        effectiveness = _expit(s) * (row[self._i_hq] > 0.5)
+        reward = float(-1000 / 152 * baseline * (1 - effectiveness * action))
+        if action == 1 and self.at_budget:  # dead branch: action is the *actual* action (Q5)
+            reward = -1
+        return reward
+
+    def _get_info(self):
+        return {
+            "episode_index": self.ep_index,
+            "remaining_budget": self.remaining_budget,
+            "at_budget": self.at_budget,
+            "feature_names": self.feat_names,
+            "location": self.location,
+            "location_index": self.location_index,
+        }
+
+    # env.py:238-262
+    def step(self, action: int):
+        self.attempted_alert_buffer.append(action)
+        self.at_budget = sum(self.actual_alert_buffer) == self.budget
+        actual_action = 0 if (action == 1 and self.at_budget) else action
+        self.actual_alert_buffer.append(actual_action)
+        if actual_action == 1:
+            self.remaining_budget -= 1
+        reward = self._get_reward(actual_action)
+        done = self.t >= self.n_days - 1
+        if not done:
+            self.observation = self._get_obs()
+            self.t += 1
+            self.alert_streak = self.alert_streak + 1 if actual_action else 0
+        return self.observation, reward, done, False, self._get_info()
+
+
+def numpy_parity_reset_tuple(d: RefData, seed: int, location: str | None, augment: bool,
+                             sticky_budget: int | None, budget_kw: int | None, sample_budget: bool,
+                             sample_budget_type: str):
+    """The draws of env.py:145-177 replayed without an env object. Returns
+    (weather_fips, coef_col, year, coef_index, budget, info_location)."""
+    rng = np.random.default_rng(seed)
+    if location is None:
+        location = str(rng.choice(d.fips_list))
+    if augment:
+        locs = [x for x in similar_counties(location, d.conf_fips, d.conf_zone) if x in d.fips_list]
+        li = int(rng.choice(range(len(locs))))
+        info_loc = locs[li]
+    else:
+        li = d.fips_list.index(location)
+        info_loc = location
+    year = int(rng.choice(d.valid_years))
+    ep = d.episodes[(location, year)]
+    ci = int(rng.integers(0, d.n_samples))
+    b = sticky_budget
+    if b is None:
+        b = int(ep[0, d.columns.index("remaining_budget")]) if budget_kw is None else budget_kw
+    if sample_budget:
+        if sample_budget_type == "less_than":
+            b = int(rng.integers(0, b + 1))
+        elif sample_budget_type == "centered":
+            b = int(rng.integers(0.5 * b, 1.5 * b + 1))
+    return location, li, year, ci, b, info_loc
+
+
+# --------------------------------------------------------------------------------------
+# Vectorised oracle (float64, same arithmetic and summation order as OracleEnv)
+# --------------------------------------------------------------------------------------
+class VectorOracle:
+    """N independent envs stepped together on dense tables.
+
+    X    f64 [S_w, Y, T, C]   episode rows, C = len(columns) (significance coded)
+    wb/we f32 [K, n_samples, S]
+    Episode tuple per env: county_w (row of X), year_i, coef_col, sample, budget, n_days.
+    """
+
+    def __init__(self, d: RefData, fips_weather: list[str], years: list[int]):
+        self.d = d
+        self.fips_weather, self.years = list(fips_weather), [int(y) for y in years]
+        T = max(v.shape[0] for v in d.episodes.values())
+        C = len(d.columns)
+        self.X = np.zeros((len(fips_weather), len(years), T, C), np.float64)
+        self.n_days_tab = np.zeros((len(fips_weather), len(years)), np.int64)
+        for ci, f in enumerate(fips_weather):
+            for yi, y in enumerate(self.years):
+                ep = d.episodes.get((f, y))
+                if ep is not None:
+                    self.X[ci, yi, : ep.shape[0]] = ep
+                    self.n_days_tab[ci, yi] = ep.shape[0]
+        self.bcols = d.key_columns(d.baseline_keys, "baseline_")
+        self.ecols = d.key_columns(d.effectiveness_keys, "effectiveness_")
+        self.i_lag1 = d.columns.index("alert_lag1")
+        self.i_streak = d.columns.index("alert_streak")
+        self.i_rem = d.columns.index("remaining_budget")
+        self.i_hq = d.columns.index("heat_qi")
+        self.C = C
+
+    def default_budget(self, county_w, year_i):
+        return self.X[county_w, year_i, 0, self.i_rem].astype(np.int64)
+
+    def reset(self, county_w, year_i, coef_col, sample, budget):
+        n = len(county_w)
+        self.county_w = np.asarray(county_w, np.int64)
+        self.year_i = np.asarray(year_i, np.int64)
+        self.coef_col = np.asarray(coef_col, np.int64)
+        self.sample = np.asarray(sample, np.int64)
+        self.budget = np.asarray(budget, np.int64)
+        self.n_days = self.n_days_tab[self.county_w, self.year_i]
+        self.t = np.zeros(n, np.int64)
+        self.used = np.zeros(n, np.int64)
+        self.streak = np.zeros(n, np.int64)
+        self.hist = np.zeros((n, 14), np.int64)  # last 14 actual actions, newest last
+        self.last_actual = np.zeros(n, np.int64)
+        self.at_budget = np.zeros(n, np.bool_)
+        self.obs = self._get_obs()
+        return self.obs.copy()
+
+    def _get_obs(self):
+        n = len(self.t)
+        row = np.empty((n, self.C + 1), np.float64)
+        row[:, :-1] = self.X[self.county_w, self.year_i, self.t]
+        row[:, self.i_lag1] = np.where(self.t > 0, self.last_actual, 0)
+        row[:, -1] = self.hist.sum(axis=1)
+        row[:, self.i_streak] = self.streak
+        row[:, self.i_rem] = self.budget - self.used
+        return row
+
+    def step(self, action):
+        action = np.asarray(action, np.int64)
+        self.at_budget = self.used == self.budget
+        actual = np.where((action == 1) & self.at_budget, 0, action)
+        self.hist = np.concatenate([self.hist[:, 1:], actual[:, None]], axis=1)
+        self.last_actual = actual
+        self.used = self.used + actual
+        row = self._get_obs()
+        zb = np.zeros(len(action), np.float64)
+        for j, c in enumerate(self.bcols):
+            x = 1.0 if c < 0 else row[:, c]
+            zb = zb + x * self.d.wb[j, self.sample, self.coef_col].astype(np.float64)
+        ze = np.zeros(len(action), np.float64)
+        for j, c in enumerate(self.ecols):
+            x = 1.0 if c < 0 else row[:, c]
+            ze = ze + x * self.d.we[j, self.sample, self.coef_col].astype(np.float64)
+        baseline = _expit(zb)
+        eff = _expit(ze) * (row[:, self.i_hq] > 0.5)
+        reward = -1000 / 152 * baseline * (1 - eff * actual)
+        done = self.t >= self.n_days - 1
+        nd = ~done
+        self.obs[nd] = row[nd]  # terminal step returns the stale observation (Q6)
+        self.t = np.where(nd, self.t + 1, self.t)
+        self.streak = np.where(nd, np.where(actual == 1, self.streak + 1, 0), self.streak)
+        return self.obs.copy(), reward, done, actual
+
+
+# --------------------------------------------------------------------------------------
+# Restatement of the build's counter-based device RNG (no reference counterpart)
+# --------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+DRAW_COUNTY, DRAW_SIMILAR, DRAW_YEAR, DRAW_SAMPLE, DRAW_BUDGET = 0, 1, 2, 3, 4
+
+
+def _mix64(z: int) -> int:
+    z &= _M64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & _M64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & _M64
+    z ^= z >> 31
+    return z
+
+
+def devrng_stream(seed: int, env_gid: int, episode_no: int) -> int:
+    h = _mix64(seed + 0x9E3779B97F4A7C15 * (env_gid + 1))
+    return _mix64(h ^ ((episode_no * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & _M64))
+
+
+def devrng_bounded(stream: int, slot: int, n: int) -> int:
+    """uniform in [0, n): high 32 bits of the slot's word, multiply-shift."""
+    u = _mix64(stream + (slot + 1) * 0x9E3779B97F4A7C15) >> 32
+    return (u * n) >> 32
+
+
+def devrng_reset_tuple(seed, env_gid, episode_no, S, n_years, n_samples, fips_to_weather, sim_ptr, sim_cnt,
+                       augment, default_budget_fn, sticky_budget, budget_kw, sample_mode):
+    """Episode tuple the device reset kernel must produce for one env.
+    sample_mode: 0 none, 1 less_than, 2 centered. sticky_budget < 0 means unset."""
+    st = devrng_stream(seed, env_gid, episode_no)
+    county = devrng_bounded(st, DRAW_COUNTY, S)
+    coef_col = devrng_bounded(st, DRAW_SIMILAR, int(sim_cnt[county])) if augment else county
+    year_i = devrng_bounded(st, DRAW_YEAR, n_years)
+    sample = devrng_bounded(st, DRAW_SAMPLE, n_samples)
+    cw = int(fips_to_weather[county])
+    b = sticky_budget
+    if b < 0:
+        b = default_budget_fn(cw, year_i) if budget_kw < 0 else budget_kw
+    base = b
+    if sample_mode == 1:
+        b = devrng_bounded(st, DRAW_BUDGET, base + 1)
+    elif sample_mode == 2:
+        lo = int(0.5 * base)
+        hi = int(1.5 * base + 1)
+        b = lo + devrng_bounded(st, DRAW_BUDGET, hi - lo)
+    return cw, coef_col, year_i, sample, b
