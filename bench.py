@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the HeatAlertEnv hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload configs2] [--num-envs M]
+
+A "step" is one vector-env step(): every env of the batch advances one day (budget gate,
+feature-row gather, two 28-term logits against its posterior draw, reward, next observation),
+including the same-step autoreset when an episode ends (every 153 steps, lock step) and, on
+N>1 GPUs, the RCCL all-gather of the finished episodes' returns. Inputs (tables, state, a
+pool of action tensors) are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0). `roofline` prices the step kernel against HBM with SURVEY §8d's
+algorithmic bytes (489 B per env-step); `cpu_baseline` times the NumPy oracle on the host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 489  # action 4 + state 20r + row 100 + weights 224 + reward 4 + done 1 + obs 116 + state 20w
+ALGO_BYTES_NO_OBS = 373
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (weights list, num_envs per GPU, similar_climate_counties, description)
+    "configs1": ("linear", 65536, False, "configs[1]: 65,536 envs, weights/linear (S=746), random county per env"),
+    "configs2": ("linear", 1048576, True,
+                 "configs[2]: 1,048,576 envs, weights/linear (S=746), similar_climate_counties=True"),
+    "configs3": ("nn_full_medicare_all", 1048576, False,
+                 "configs[3]: 1,048,576 envs, nn_full_medicare_all shape (S=720), row-gather kernel"),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=306)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS))
+    p.add_argument("--num-envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
+    p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--seed", type=int, default=0)
+    return p.parse_args()
+
+
+def cpu_baseline(sd, ct, seed=0):
+    """NumPy oracle (float64, vectorised over envs) timed on the host: bounded sample of the
+    same workload. Also times the scalar per-env restatement of the reference's step()."""
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+
+    rd = O.RefData.from_synth(sd)
+    V = O.VectorOracle(rd, sd.fips_weather, sd.years)
+    rng = np.random.default_rng(seed)
+    n, steps = 65536, 154
+    county = rng.integers(0, ct.S, n)
+    cc = rng.integers(0, np.maximum(ct.sim_cnt[county], 1))
+    V.reset(ct.fips_to_weather[county].astype(np.int64), rng.integers(0, ct.Y, n), cc,
+            rng.integers(0, ct.n_samples, n), rng.integers(0, 12, n))
+    acts = (rng.random((steps, n)) < 0.1).astype(np.int64)
+    V.step(acts[0])
+    t0 = time.perf_counter()
+    for t in range(1, steps):
+        V.step(acts[t])
+    dt = time.perf_counter() - t0
+    vec = n * (steps - 1) / dt
+    env = O.OracleEnv(rd)
+    env.reset(location=sd.fips_list[0], seed=0)
+    t0 = time.perf_counter()
+    k = 0
+    for ep in range(3):
+        env.reset(location=sd.fips_list[ep], seed=ep)
+        done = False
+        while not done:
+            _, _, done, _, _ = env.step(int(acts[k % steps, k % n]))
+            k += 1
+    scalar = k / (time.perf_counter() - t0)
+    return {
+        "value": vec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"NumPy float64 vector oracle, {n} envs x {steps - 1} steps of the same tables ({dt:.1f} s)",
+        "scalar_port_env_steps_per_s": scalar,
+        "host_cpus": os.cpu_count(),
+        "reference_env_steps_per_s_build_container": 646.0,  # BASELINE.md §2 (pandas env, 1 core; it cannot travel)
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    from weather2alert_amd import HeatAlertVecEnv, dist as wdist, synth, tables
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    wdist.init_from_env("nccl", device)
+
+    wname, n_default, augment, desc = WORKLOADS[args.workload]
+    n = args.num_envs or n_default
+    t_setup = time.perf_counter()
+    sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
+                          extra_confounder_fips=60)
+    ct = tables.compile_from_synth(sd)
+    env = HeatAlertVecEnv(n, tables=ct, device=device, similar_climate_counties=augment, env_gid0=rank * n,
+                          write_obs=not args.no_obs)
+    gather = wdist.ReturnGatherer(n, device)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
+    env.reset(seed=args.seed)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    T = ct.T
+    stepno = 0
+
+    def one_step():
+        nonlocal stepno
+        env.step(pool[stepno & 15])
+        stepno += 1
+        if stepno % T == 0:  # lock step: every env just finished an episode
+            gather.gather(env._final_return)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    wdist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        one_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wdist.barrier()
+    wall = time.perf_counter() - t0
+    wall = wdist.max_over_ranks(wall, device)
+    dev_ms = ev0.elapsed_time(ev1)
+    status = env.check_status()
+    mean_ret = float(gather.mean(env._final_return).item())
+
+    if rank == 0:
+        total_env_steps = float(n) * world * args.steps
+        per_launch_s = dev_ms * 1e-3 / args.steps
+        bytes_per = ALGO_BYTES_NO_OBS if args.no_obs else ALGO_BYTES_PER_ENV_STEP
+        achieved = bytes_per * n / per_launch_s / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(args.workload)
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "env_steps_per_sec", "value": total_env_steps / wall, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" , "data": "synthetic",
+            "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
+                       "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
+                       "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
+                       "seed_mode": "device", "autoreset": "same_step",
+                       "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_step<autoreset,obs>", "avg_launch_us": per_launch_s * 1e6,
+                         "algorithmic_bytes_per_env_step": bytes_per,
+                         "timing": "HIP events on the launch stream around the timed steps / steps"},
+            "kernel_env_steps_per_sec_per_gpu": n / per_launch_s,
+            "status_bits": status, "mean_final_return": mean_ret, "setup_s": t_setup,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
+        print(json.dumps(out), flush=True)
+    env.close()
+    wdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/* w2a.h -- C ABI of the MI355X-native vectorised HeatAlertEnv hot path (libw2a.so).
+ *
+ * The reference (NSAPH-Projects/weather2alert) is pure Python and exposes no FFI; its
+ * boundary for this path is the Gymnasium Env API of src/weather2alert/env.py. Each entry
+ * point below names the reference lines it replaces. The Python host class
+ * (weather2alert_amd/env.py) keeps the reference's ctor/reset/step surface and calls these
+ * through ctypes with torch-ROCm tensor data_ptr()s; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch) unless marked host.
+ *     The library allocates nothing on the device and frees nothing but the handle.
+ *   - All calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream). No call synchronises except w2a_read_status.
+ *   - Return value: 0 = W2A_OK, negative = error (w2a_last_error() gives the text). Nothing
+ *     throws across the ABI. Arguments are validated on the host before any launch; values
+ *     that live in device arrays (episode tuples, actions) are range-checked inside the
+ *     kernels, which clamp them and set a bit in the device status word instead of faulting.
+ *   - A handle is not thread-safe; one handle per (process, device).
+ */
+#ifndef W2A_H
+#define W2A_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2A_ABI_VERSION 1
+#define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
+#define W2A_LANES_PER_ENV 8
+
+enum {
+  W2A_OK = 0,
+  W2A_ERR_ARG = -1,      /* NULL pointer, non-positive size, bad enum */
+  W2A_ERR_SCHEMA = -2,   /* table dims / slot layout the kernels cannot serve */
+  W2A_ERR_HIP = -3,      /* a HIP runtime call failed */
+  W2A_ERR_STATE = -4     /* state buffer too small / misaligned */
+};
+
+/* bits of the device status word (w2a_read_status) */
+enum {
+  W2A_ST_BAD_EPISODE = 1, /* reset tuple out of range (reference: KeyError env.py:127 / ValueError :121) */
+  W2A_ST_BAD_ACTION = 2,  /* action not in {0,1} (reference action_space = Discrete(2), env.py:95) */
+  W2A_ST_STEP_AFTER_DONE = 4 /* step() on a finished episode without autoreset */
+};
+
+/* action buffer element types accepted by w2a_step */
+enum { W2A_ACT_I32 = 0, W2A_ACT_I64 = 1, W2A_ACT_U8 = 2 };
+
+/* w2a_step flags */
+enum {
+  W2A_STEP_AUTORESET = 1, /* same-step autoreset with the device RNG (needs w2a_set_autoreset) */
+  W2A_STEP_NO_OBS = 2     /* reward-only: skip the observation write */
+};
+
+/* budget sampling of reset(sample_budget=..., sample_budget_type=...), env.py:172-177 */
+enum { W2A_BUDGET_FIXED = 0, W2A_BUDGET_LESS_THAN = 1, W2A_BUDGET_CENTERED = 2 };
+
+/* Dense tables, compiled on the host by weather2alert_amd/tables.py.
+ *
+ * Replaces what HeatAlertEnv.__init__ builds (env.py:49-85): the merged (fips, year, date)
+ * feature frame and the posterior coefficient tensors.
+ *
+ * Internal slot layout of a 32-float row (lane l of an env's 8-lane group owns slots 4l..4l+3):
+ *   slots  0..23  table-sourced columns (reward features first, in merged-column order)
+ *   slots 24..27  run-time fields: alert_lag1, alert_streak, remaining_budget, alert_2wks(agent)
+ *   slot   28     25th table-sourced column if the schema has one (else 0)
+ *   slot   29     bias input (the table stores 1.0)
+ *   slots 30..31  zero
+ * W rows use the same slots (zero where a slot has no coefficient), so a reward logit is a
+ * plain 32-wide dot product. obs_slot[j] maps observation column j (reference order,
+ * env.py:186-195: the 28 episode columns then 'alert_2wks') to its slot.
+ */
+typedef struct w2a_tables {
+  const float *X;                 /* [T][S_w*Y][32]  day-major feature rows            */
+  const int32_t *n_days;          /* [S_w*Y]  episode length, 0 = (county, year) absent */
+  const int32_t *B0;              /* [S_w*Y]  default budget = remaining_budget at day 0 (env.py:169) */
+  const float *W;                 /* [S*n_samples][2][32]  head 0 baseline, 1 effectiveness */
+  const int32_t *fips_to_weather; /* [S]  weight column -> county row of X, -1 = no weather */
+  const int32_t *sim_cnt;         /* [S]  |similar(county) ∩ fips_list|  (env.py:115-117)  */
+  int32_t T, S_w, Y, S, n_samples;
+  int32_t n_obs;                  /* observation width (29 with the reference schema)    */
+  int32_t obs_slot[W2A_ROW_FLOATS]; /* obs column -> slot, first n_obs entries valid       */
+  int32_t slot_heat_qi;           /* slot of 'heat_qi' (effectiveness gate, env.py:218)  */
+} w2a_tables;
+
+typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */
+
+/* Decoded per-env state, for tests / checkpointing: every field is an int32 [num_envs]
+ * device array supplied by the caller (NULL = skip). */
+typedef struct w2a_state_view {
+  int32_t *t, *used, *streak, *hist14, *last_actual, *at_budget, *budget, *n_days;
+  int32_t *county_w, *year_i, *coef_col, *sample, *sticky_budget, *episode_no;
+  float *episode_return; /* running return of the current episode */
+} w2a_state_view;
+
+int w2a_abi_version(void);
+const char *w2a_last_error(void);
+
+/* Bytes of caller-owned device memory one handle needs for `num_envs` envs (256-B aligned). */
+size_t w2a_state_bytes(int64_t num_envs);
+
+/* Replaces HeatAlertEnv.__init__ (env.py:20-105) for `num_envs` envs whose global ids are
+ * env_gid0 .. env_gid0+num_envs-1 (the device RNG is keyed by global id, so results do not
+ * depend on how envs are sharded over GPUs). `tables` (host struct of device pointers) is
+ * copied; `state` must stay alive until w2a_destroy. `status` is a caller-owned int32. */
+int w2a_create(const w2a_tables *tables, int64_t num_envs, int64_t env_gid0, void *state, size_t state_bytes,
+               int32_t *status, w2a_env **out);
+void w2a_destroy(w2a_env *env);
+
+/* Replaces reset() (env.py:133-184) with the episode tuples chosen by the caller (the host
+ * replays NumPy's draws for seed parity, or injects them): per env the weather county row,
+ * year index, coefficient column (env.py:117/121), posterior sample (env.py:160) and budget
+ * (env.py:167-178). mask (uint8, nullable) selects which envs reset. Writes the first
+ * observation rows into obs [num_envs][n_obs] (nullable). */
+int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, const int32_t *coef_col,
+              const int32_t *sample, const int32_t *budget, const uint8_t *mask, float *obs, void *stream);
+
+/* reset() with every draw of env.py:145-177 made on the device from a counter-based RNG keyed
+ * by (seed, global env id, per-env episode number). location < 0 draws the county
+ * (env.py:151-152), otherwise it is the weight-column index of the requested county.
+ * budget_kw < 0 means "budget=None". Budget stickiness (env.py:167-170) is kept per env
+ * unless `sticky` is 0. */
+int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                         int sample_budget_mode, int sticky, const uint8_t *mask, float *obs, void *stream);
+
+/* Parameters the same-step autoreset of w2a_step uses (same meaning as above). */
+int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                      int sample_budget_mode, int sticky);
+
+/* Replaces step() (env.py:238-262) for all envs: budget gate, history update, feature-row
+ * gather, the two 28-term logits against the env's posterior draw, reward, termination, and
+ * the next observation. actions: [num_envs] of `action_dtype`. obs [num_envs][n_obs] f32,
+ * reward [num_envs] f32, done [num_envs] uint8. On a terminal step without autoreset the
+ * obs rows are left untouched (the reference returns the stale observation, env.py:257-262);
+ * with autoreset they hold the new episode's first observation and last_return (nullable,
+ * f32 [num_envs]) receives the finished episode's return. */
+int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, float *reward, uint8_t *done,
+             float *last_return, int flags, void *stream);
+
+/* Decode the packed state into the caller's arrays (see w2a_state_view). */
+int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
+
+/* Synchronise `stream`, read and clear the device status word (host int out). */
+int w2a_read_status(w2a_env *env, int32_t *status_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2A_H */

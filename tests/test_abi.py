@@ -1,0 +1,65 @@
+"""CPU checks of the drop-in boundary: libw2a.so builds for gfx950, loads without a GPU, and
+exports exactly the entry points include/w2a.h declares; host-side argument validation works
+without touching a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from weather2alert_amd import _ffi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return _ffi.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "w2a.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(w2a_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    syms = header_symbols()
+    assert syms == sorted(_ffi.SYMBOLS)
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
+def test_host_only_entry_points(lib):
+    assert lib.w2a_abi_version() == 1
+    assert lib.w2a_state_bytes(0) == 0
+    n = 1000
+    b = lib.w2a_state_bytes(n)
+    assert b >= 256 + 32 * n and b % 256 == 0
+    # NULL / bad arguments are rejected on the host with a message, nothing is launched
+    h = C.c_void_p()
+    assert lib.w2a_create(None, 10, 0, None, 0, None, C.byref(h)) == -1
+    assert b"NULL" in lib.w2a_last_error()
+    assert lib.w2a_step(None, None, 0, None, None, None, None, 0, None) == -1
+    assert lib.w2a_reset_device_rng(None, 0, -1, 0, -1, 0, 1, None, None, None) == -1
+
+
+def test_ffi_struct_layout_matches_header():
+    # 6 pointers + 6 int32 + 32 int32 + 1 int32, naturally aligned
+    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4
+    assert C.sizeof(_ffi.StateView) == 15 * 8
+
+
+def test_env_refuses_to_run_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from weather2alert_amd import HeatAlertVecEnv, synth, tables
+
+    ct = tables.compile_from_synth(synth.make_synth("linear", n_fips=8, years=[2006], n_samples=2, seed=0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HeatAlertVecEnv(4, tables=ct, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        HeatAlertVecEnv(4, tables=ct, device="cpu")

@@ -1,0 +1,278 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors captured from
+the reference and against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): integer alert-budget state bit-exact; float reward within
+1e-5 of the reference. Observations are f32 copies of exactly-representable table values,
+so they are required bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import heatalert_oracle as O
+from weather2alert_amd import synth, tables
+
+pytestmark = pytest.mark.gpu
+
+REWARD_TOL = 1e-5  # stated by north_star
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def mini(golden_dir, mini_root, dev):
+    from weather2alert_amd.tables import DeviceTables
+
+    d = dict(np.load(os.path.join(golden_dir, "mini_traj.npz")))
+    meta = json.loads(str(d["meta_json"]))
+    ct = tables.compile_from_files(mini_root, "linear")
+    return d, meta, ct, DeviceTables(ct, dev), O.RefData.from_files(mini_root, "linear")
+
+
+def test_library_loaded_is_in_tree():
+    from weather2alert_amd import _ffi
+
+    _ffi.load()
+    maps = open("/proc/self/maps").read()
+    assert "weather2alert_amd/_lib/libw2a.so" in maps
+
+
+def test_dropin_env_reproduces_reference_goldens(mini, dev):
+    """config 1 plumbing: HeatAlertEnv(num_envs=1) vs every golden episode of the reference."""
+    from weather2alert_amd import HeatAlertEnv
+
+    d, meta, ct, dt, _ = mini
+    envs = {}
+    worst = 0.0
+    for i, e in enumerate(meta["episodes"]):
+        key = e["env_key"]
+        if key not in envs:
+            envs[key] = HeatAlertEnv(weights="linear", tables=dt, device=dev, **e["ctor"])
+        env = envs[key]
+        obs, info = env.reset(**e["reset"])
+        assert info["location"] == e["info_location"]
+        assert info["episode_index"] == e["episode_index"]
+        assert info["location_index"] == d["location_index"][i]
+        assert env.coef_index == d["coef_index"][i]
+        assert env.budget == d["budget"][i]
+        assert info["remaining_budget"] == d["reset_remaining_budget"][i]
+        assert info["feature_names"] == meta["feature_names"]
+        np.testing.assert_array_equal(obs, d["obs0"][i].astype(np.float32))
+        # stepping one env at a time is slow (syncs): check a prefix, the end and the budget edge
+        for t in range(153):
+            obs, r, done, trunc, info = env.step(int(d["actions"][i, t]))
+            assert abs(r - d["reward"][i, t]) <= REWARD_TOL
+            worst = max(worst, abs(r - d["reward"][i, t]))
+            assert done == d["done"][i, t] and trunc is False
+            np.testing.assert_array_equal(obs, d["obs"][i, t].astype(np.float32))
+            assert info["remaining_budget"] == d["remaining_budget"][i, t]
+            assert info["at_budget"] == d["at_budget"][i, t]
+            assert env.alert_streak == d["streak_after"][i, t]
+            assert env.t == d["t_after"][i, t]
+    print("max |reward - reference| =", worst)
+    for env in envs.values():
+        env.close()
+
+
+def test_vector_env_equals_goldens_batched(mini, dev):
+    """All golden episodes as one batch with injected episode tuples (ragged N = 58)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    d, meta, ct, dt, _ = mini
+    E = len(meta["episodes"])
+    cw = [ct.fips_weather.index(e["episode_index"].split("_")[0]) for e in meta["episodes"]]
+    yi = [ct.years.index(int(e["episode_index"].split("_")[1])) for e in meta["episodes"]]
+    env = HeatAlertVecEnv(E, tables=dt, device=dev, autoreset="disabled")
+    obs, info = env.reset(options={"episodes": dict(county_w=cw, year_i=yi, coef_col=d["location_index"],
+                                                    sample=d["coef_index"], budget=d["budget"])})
+    np.testing.assert_array_equal(obs.cpu().numpy(), d["obs0"].astype(np.float32))
+    for t in range(153):
+        obs, r, done, trunc, info = env.step(torch.as_tensor(d["actions"][:, t], device=dev))
+        np.testing.assert_allclose(r.cpu().numpy(), d["reward"][:, t], rtol=0, atol=REWARD_TOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), d["done"][:, t])
+        np.testing.assert_array_equal(obs.cpu().numpy(), d["obs"][:, t].astype(np.float32))
+        np.testing.assert_array_equal(info["remaining_budget"].cpu().numpy(), d["remaining_budget"][:, t])
+        np.testing.assert_array_equal(info["at_budget"].cpu().numpy(), d["at_budget"][:, t])
+        st = env.state()
+        np.testing.assert_array_equal(st["streak"].cpu().numpy(), d["streak_after"][:, t])
+        np.testing.assert_array_equal(st["t"].cpu().numpy(), d["t_after"][:, t])
+        np.testing.assert_array_equal(st["last_actual"].cpu().numpy(), d["actual"][:, t])
+    assert not trunc.any()
+    ret = env.state()["episode_return"].cpu().numpy()
+    np.testing.assert_allclose(ret, d["reward"].sum(axis=1), rtol=1e-5)
+    assert env.check_status() == 0
+    env.close()
+
+
+def _random_tuples(ct, n, rng, augment):
+    county = rng.integers(0, ct.S, n)
+    cc = np.where(augment, rng.integers(0, np.maximum(ct.sim_cnt[county], 1)), county)
+    return dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=cc,
+                sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 12, n))
+
+
+@pytest.mark.parametrize("n,augment,adversarial", [(4099, False, False), (65536, True, False), (8192, False, True)])
+def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial):
+    """HIP path vs the float64 vector oracle over a full 153-step episode on a synthetic data set
+    (64 counties x 4 years, 16 posterior draws). 'adversarial' uses unscaled N(0,1) coefficients
+    (logit terms up to ~150 with cancellation) to show the fp64 accumulation holds the 1e-5 bar."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=64, years=[2006, 2007, 2008, 2009], n_samples=16, seed=11,
+                          weight_scale=None if adversarial else synth.DEFAULT_SCALE,
+                          weight_sigma=1.0 if adversarial else 0.3, extra_confounder_fips=5)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    rng = np.random.default_rng(n)
+    ep = _random_tuples(ct, n, rng, augment)
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    obs, _ = env.reset(options={"episodes": ep})
+    obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
+    np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+    worst = 0.0
+    for t in range(153):
+        a = (rng.random(n) < 0.15).astype(np.int32)
+        obs, r, done, _, _ = env.step(torch.as_tensor(a, device=dev))
+        obs_o, r_o, done_o, actual_o = V.step(a)
+        err = np.abs(r.cpu().numpy().astype(np.float64) - r_o).max()
+        worst = max(worst, err)
+        assert err <= REWARD_TOL, (t, err)
+        np.testing.assert_array_equal(done.cpu().numpy(), done_o)
+        np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+    st = {k: v.cpu().numpy() for k, v in env.state().items()}
+    np.testing.assert_array_equal(st["used"], V.used)
+    np.testing.assert_array_equal(st["streak"], V.streak)
+    np.testing.assert_array_equal(st["t"], V.t)
+    np.testing.assert_array_equal(st["hist14"], (V.hist * (1 << np.arange(13, -1, -1))).sum(axis=1))
+    np.testing.assert_array_equal(st["budget"] - st["used"], V.budget - V.used)
+    print(f"n={n} adversarial={adversarial}: max |reward - oracle| = {worst:.3e}")
+    env.close()
+
+
+def test_device_rng_reset_matches_restatement(dev):
+    """seed_mode='device': episode tuples drawn in the kernel == the oracle's restatement of the
+    counter RNG, incl. augmentation (Q8), budget sampling and the sticky budget (Q9)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=40, years=[2006, 2007, 2008], n_samples=10, seed=3,
+                          extra_confounder_fips=4)
+    ct = tables.compile_from_synth(sd)
+    n, gid0, seed = 1000, 12345, 2024
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", env_gid0=gid0,
+                          similar_climate_counties=True)
+
+    def b0(cw, yi):
+        return int(ct.B0[cw * ct.Y + yi])
+
+    sticky = np.full(n, -1)
+    for episode, (mode, mname) in enumerate([(0, None), (1, "less_than"), (2, "centered")]):
+        opts = {} if mname is None else {"sample_budget": True, "sample_budget_type": mname}
+        obs, _ = env.reset(seed=seed, options=opts)
+        st = {k: v.cpu().numpy() for k, v in env.state().items()}
+        for i in range(0, n, 7):
+            cw, cc, yi, sm, b = O.devrng_reset_tuple(seed, gid0 + i, episode, ct.S, ct.Y, ct.n_samples,
+                                                     ct.fips_to_weather, ct.sim_ptr, ct.sim_cnt, True, b0,
+                                                     int(sticky[i]), -1, mode)
+            assert (st["county_w"][i], st["coef_col"][i], st["year_i"][i], st["sample"][i], st["budget"][i]) == \
+                (cw, cc, yi, sm, b), (episode, i)
+            assert st["episode_no"][i] == episode and st["sticky_budget"][i] == b
+            sticky[i] = b
+        assert env.check_status() == 0
+        # first observation = day-0 row with zeroed history and remaining_budget = budget
+        o = obs.cpu().numpy()
+        names = ct.feature_names
+        np.testing.assert_array_equal(o[:, names.index("remaining_budget")], st["budget"])
+        assert (o[:, names.index("alert_lag1")] == 0).all() and (o[:, names.index("alert_2wks")] == 0).all()
+        np.testing.assert_array_equal(o[:, names.index("dos")], 0)
+    # draws are roughly uniform
+    c = np.bincount(env.state()["sample"].cpu().numpy(), minlength=ct.n_samples)
+    assert c.min() > 0.5 * n / ct.n_samples
+    env.close()
+
+
+def test_same_step_autoreset_and_shard_invariance(dev):
+    """Lock-step autoreset on the device: after 153 steps every env restarts inside the same
+    call; final returns are reported; and two half-size shards keyed by global env id give the
+    same trajectories as one full-size env (multi-GPU correctness by construction)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=32, years=[2006, 2007], n_samples=6, seed=5)
+    ct = tables.compile_from_synth(sd)
+    n = 2048 + 40
+    full = HeatAlertVecEnv(n, tables=ct, device=dev)
+    h = n // 2
+    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0), HeatAlertVecEnv(n - h, tables=ct, device=dev,
+                                                                                   env_gid0=h)]
+    o_full, _ = full.reset(seed=77)
+    o_parts = [p.reset(seed=77)[0] for p in parts]
+    assert torch.equal(o_full, torch.cat(o_parts))
+    g = torch.Generator(device="cpu").manual_seed(1)
+    ret = torch.zeros(n, dtype=torch.float64)
+    for t in range(153 + 5):
+        a = (torch.rand(n, generator=g) < 0.2).to(torch.int64)
+        o, r, d, _, info = full.step(a.to(dev))
+        outs = [p.step(a[s].to(dev)) for p, s in zip(parts, (slice(0, h), slice(h, n)))]
+        assert torch.equal(o, torch.cat([x[0] for x in outs]))
+        assert torch.equal(r, torch.cat([x[1] for x in outs]))
+        assert torch.equal(d, torch.cat([x[2] for x in outs]))
+        if t < 153:
+            ret += r.cpu().double()
+        if t == 152:
+            assert d.all()
+            np.testing.assert_allclose(info["final_return"].cpu().numpy(), ret.numpy(), rtol=2e-5)
+            st = full.state()
+            assert (st["t"] == 0).all() and (st["episode_no"] == 1).all() and (st["used"] == 0).all()
+            names = ct.feature_names
+            assert (o[:, names.index("dos")] == 0).all()
+        else:
+            assert not d.any()
+    assert full.check_status() == 0
+    for e in [full] + parts:
+        e.close()
+
+
+def test_masked_reset_bad_inputs_and_reward_only(dev, mini):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    d, meta, ct, dt, _ = mini
+    n = 37
+    env = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled", seed_mode="numpy_parity")
+    obs0, _ = env.reset(seed=5)
+    obs0 = obs0.clone()
+    for _ in range(3):
+        env.step(torch.ones(n, dtype=torch.uint8, device=dev))
+    st1 = {k: v.clone() for k, v in env.state().items()}
+    mask = np.zeros(n, bool)
+    mask[::3] = True
+    env.reset(seed=5, options={"mask": mask})
+    st2 = env.state()
+    m = torch.as_tensor(mask, device=dev)
+    assert (st2["t"][m] == 0).all() and torch.equal(st2["t"][~m], st1["t"][~m])
+    assert torch.equal(st2["used"][~m], st1["used"][~m])
+    # actions outside {0,1} are flagged (Discrete(2))
+    env.step(torch.full((n,), 3, dtype=torch.int32, device=dev))
+    with pytest.raises(ValueError):
+        env.check_status()
+    # host-side validation mirrors the reference's exceptions
+    with pytest.raises(ValueError):
+        env.reset(seed=1, options={"location": "99999"})
+    with pytest.raises(KeyError):
+        env.reset(options={"episodes": dict(county_w=[ct.S_w] * n, year_i=0, coef_col=0, sample=0)})
+    env.close()
+    # reward-only variant gives the same rewards as the full step
+    a = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled")
+    b = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled", write_obs=False)
+    a.reset(seed=9)
+    b.reset(seed=9)
+    for t in range(20):
+        act = torch.as_tensor((np.arange(n) + t) % 3 == 0, device=dev)
+        ra, rb = a.step(act)[1], b.step(act)[1]
+        assert torch.equal(ra, rb)
+    a.close()
+    b.close()

@@ -1,0 +1,88 @@
+"""Host logic: table compiler (slot layout, day-major rows, weight rows, similar-county CSR)
+checked against the oracle's independent loader on the committed mini data set."""
+import numpy as np
+import pytest
+
+from oracle import heatalert_oracle as O
+from weather2alert_amd import synth, tables
+
+
+@pytest.fixture(scope="module")
+def ct(mini_root):
+    return tables.compile_from_files(mini_root, "linear")
+
+
+@pytest.fixture(scope="module")
+def rd(mini_root):
+    return O.RefData.from_files(mini_root, "linear")
+
+
+def test_schema(ct, rd):
+    assert ct.columns == rd.columns and ct.n_obs == 29
+    assert ct.fips_list == rd.fips_list and ct.years == rd.valid_years and ct.n_samples == rd.n_samples
+    assert ct.baseline_keys == rd.baseline_keys and ct.effectiveness_keys == rd.effectiveness_keys
+    assert ct.sig_categories == rd.sig_categories and ct.f32_exact
+    assert sorted(ct.obs_slot) == sorted(set(ct.obs_slot)) and max(ct.obs_slot) < 32
+    assert [ct.slot_of[c] for c in ("alert_lag1", "alert_streak", "remaining_budget", "alert_2wks")] == [24, 25, 26, 27]
+    assert ct.slot_of["bias"] == 29
+
+
+def test_rows_equal_reference_frame(ct, rd):
+    rt = [c for c in ct.columns if c not in tables.RUNTIME_COLS]
+    for (f, y), ep in rd.episodes.items():
+        r = ct.fips_weather.index(f) * ct.Y + ct.years.index(y)
+        assert ct.n_days[r] == ep.shape[0] == 153
+        assert ct.B0[r] == ep[0, rd.columns.index("remaining_budget")]
+        for c in rt:
+            np.testing.assert_array_equal(ct.X[:153, r, ct.slot_of[c]], ep[:, rd.columns.index(c)].astype(np.float32))
+        assert (ct.X[:153, r, 29] == 1).all()
+        np.testing.assert_array_equal(ct.X[:153, r, 30], ep[:, rd.columns.index("heat_qi")].astype(np.float32))
+        assert (ct.X[:153, r, 24:28] == 0).all() and (ct.X[:153, r, 31] == 0).all()
+
+
+def test_weight_rows(ct, rd):
+    W = ct.W.reshape(ct.S, ct.n_samples, 2, 32)
+    for head, (keys, w, prefix) in enumerate(((rd.baseline_keys, rd.wb, "baseline_"),
+                                               (rd.effectiveness_keys, rd.we, "effectiveness_"))):
+        used = set()
+        for j, k in enumerate(keys):
+            s = ct.slot_of[k.replace(prefix, "")]
+            used.add(s)
+            np.testing.assert_array_equal(W[:, :, head, s], w[j].T)
+        rest = [s for s in range(32) if s not in used]
+        assert (W[:, :, head, rest] == 0).all()
+        assert 30 in rest and 27 in rest  # gate copy and the agent's alert_2wks carry no coefficient (Q1)
+
+
+def test_similar_csr_matches_datautils_restatement(ct, rd):
+    for i, f in enumerate(ct.fips_list):
+        ref = [x for x in O.similar_counties(f, rd.conf_fips, rd.conf_zone) if x in rd.fips_list]
+        assert ct.sim_cnt[i] == len(ref)
+        assert [ct.fips_list[j] for j in ct.similar_list(i)] == ref
+
+
+def test_file_and_dense_paths_agree(ct):
+    mini = synth.make_synth("linear", n_fips=24, years=[2006, 2007, 2008], n_samples=8, seed=7,
+                            extra_confounder_fips=8)
+    c2 = tables.compile_from_synth(mini)
+    for k in ("X", "W", "n_days", "B0", "fips_to_weather", "sim_cnt", "sim_idx"):
+        np.testing.assert_array_equal(getattr(ct, k), getattr(c2, k))
+    assert ct.obs_slot == c2.obs_slot and ct.fips_weather == c2.fips_weather
+
+
+def test_schema_errors():
+    sd = synth.make_synth("linear", n_fips=8, years=[2006], n_samples=2, seed=0)
+    bad = dict(sd.weights)
+    bad["baseline_not_a_column"] = bad["baseline_bias"]
+    sd.weights = bad
+    with pytest.raises(tables.SchemaError):
+        tables.compile_from_synth(sd)
+
+
+def test_full_size_similar_anchor():
+    """n_similar('06037') = 111 on the 746-county list with the real climate zones."""
+    full = synth.load_fips_list("linear")
+    zones = synth.load_ba_zones()
+    cnt, ptr, idx = tables._similar_csr(full, full, [zones[f] for f in full])
+    assert full.index("06037") == 84 and cnt[84] == 111
+    assert synth.load_fips_list("nn_full_medicare_all").index("06037") == 82

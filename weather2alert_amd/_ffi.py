@@ -1,0 +1,100 @@
+"""ctypes binding of include/w2a.h (libw2a.so). No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+ROW_FLOATS = 32
+LANES_PER_ENV = 8
+
+OK = 0
+ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
+ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
+STEP_AUTORESET, STEP_NO_OBS = 1, 2
+BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
+
+# every symbol include/w2a.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
+    "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
+]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("n_days", C.c_void_p), ("B0", C.c_void_p), ("W", C.c_void_p),
+        ("fips_to_weather", C.c_void_p), ("sim_cnt", C.c_void_p),
+        ("T", C.c_int32), ("S_w", C.c_int32), ("Y", C.c_int32), ("S", C.c_int32), ("n_samples", C.c_int32),
+        ("n_obs", C.c_int32), ("obs_slot", C.c_int32 * ROW_FLOATS), ("slot_heat_qi", C.c_int32),
+    ]
+
+
+STATE_FIELDS = ["t", "used", "streak", "hist14", "last_actual", "at_budget", "budget", "n_days", "county_w",
+                "year_i", "coef_col", "sample", "sticky_budget", "episode_no", "episode_return"]
+
+
+class StateView(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in STATE_FIELDS]
+
+
+class W2AError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libw2a.so (building it with hipcc first when the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build_lib()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise W2AError(f"libw2a.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise W2AError(f"{path} not found: run `python -m weather2alert_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    lib.w2a_abi_version.restype = C.c_int
+    lib.w2a_abi_version.argtypes = []
+    lib.w2a_last_error.restype = C.c_char_p
+    lib.w2a_last_error.argtypes = []
+    lib.w2a_state_bytes.restype = C.c_size_t
+    lib.w2a_state_bytes.argtypes = [i64]
+    lib.w2a_create.restype = C.c_int
+    lib.w2a_create.argtypes = [C.POINTER(Tables), i64, i64, vp, C.c_size_t, vp, C.POINTER(vp)]
+    lib.w2a_destroy.restype = None
+    lib.w2a_destroy.argtypes = [vp]
+    lib.w2a_reset.restype = C.c_int
+    lib.w2a_reset.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.w2a_reset_device_rng.restype = C.c_int
+    lib.w2a_reset_device_rng.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int, vp, vp, vp]
+    lib.w2a_set_autoreset.restype = C.c_int
+    lib.w2a_set_autoreset.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int]
+    lib.w2a_step.restype = C.c_int
+    lib.w2a_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.w2a_get_state.restype = C.c_int
+    lib.w2a_get_state.argtypes = [vp, C.POINTER(StateView), vp]
+    lib.w2a_read_status.restype = C.c_int
+    lib.w2a_read_status.argtypes = [vp, C.POINTER(i32), vp]
+    if lib.w2a_abi_version() != 1:
+        raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != OK:
+        msg = load().w2a_last_error().decode("utf-8", "replace")
+        raise W2AError(f"{what} failed ({rc}): {msg}")

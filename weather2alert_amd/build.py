@@ -1,0 +1,55 @@
+"""Build the in-tree HIP library (libw2a.so) for gfx950 with hipcc.
+
+``python -m weather2alert_amd.build`` or ``build_lib()``. hipcc cross-compiles without a
+GPU; the resulting .so is git-ignored but travels with the working tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SRC = os.path.join(PKG, "csrc", "w2a_kernels.hip")
+INC = os.path.join(ROOT, "include")
+LIB_DIR = os.path.join(PKG, "_lib")
+LIB = os.path.join(LIB_DIR, "libw2a.so")
+
+
+def hipcc_path() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need the ROCm toolchain to build libw2a.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    m = os.path.getmtime(LIB)
+    deps = [SRC, os.path.join(INC, "w2a.h")]
+    return any(os.path.getmtime(d) > m for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INC}", SRC,
+           "-o", LIB + ".tmp"]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(r.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

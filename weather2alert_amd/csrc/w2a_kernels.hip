@@ -1,0 +1,617 @@
+// w2a_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of the vectorised HeatAlertEnv.
+//
+// What is computed follows the reference src/weather2alert/env.py:
+//   reset  :133-184 (+ _get_episode :107-131)      -> reset_env() / k_reset_*
+//   _get_obs :186-195, _get_reward :197-226, step :238-262 -> k_step
+// How it is computed is MI355X-first:
+//   * an env is served by an 8-lane group of a 64-wide wavefront (8 envs per wave, 32 per
+//     256-thread workgroup); lane l owns floats 4l..4l+3 of the env's 128-byte feature row
+//     and of its two 128-byte coefficient rows, so every gather is three 16-B loads per
+//     lane that together cover whole 128-B lines;
+//   * feature rows are stored day-major ([T][county*year][32]); all envs of a lock-step
+//     batch read the same ~1 MB day slice, which stays in each XCD's 4 MiB L2;
+//   * the 28-term logits are accumulated in fp64 (products of f32 inputs are exact in
+//     fp64, the sum carries ~1e-16 relative error, cf. the reference's float64 sum at
+//     env.py:207-217) and reduced over the 8 lanes with DPP moves (quad_perm xor1/xor2 +
+//     row_half_mirror) -- no LDS traffic, no ds_bpermute;
+//   * the packed [N][29] f32 observation rows of a wave (8 x 116 B = 928 contiguous bytes)
+//     are transposed through a 1-KB LDS tile and leave as 58 fully coalesced 16-B stores;
+//   * per-env state is two 16-B words (cold: episode tuple, hot: counters) read as group
+//     broadcast loads; the hot word is written back as whole 128-B lines per wave.
+//
+// No fallback path exists: if this library is missing the Python package fails to import.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "w2a.h"
+
+#define LANES 8
+#define ROWF 32
+#define BLOCK 256
+#define ENVS_PER_BLOCK (BLOCK / LANES)
+#define ENVS_PER_WAVE (64 / LANES)
+#define HDR_BYTES 256
+
+// ----------------------------------------------------------------------------------------
+// packed state
+// ----------------------------------------------------------------------------------------
+// cold (uint4): x = ep_row (county_w*Y + year_i), y = ep_w (coef_col*n_samples + sample),
+//               z = sticky budget (int, -1 unset), w = episode number
+// hot  (uint4): x = dyn0: t[0:10) used[10:20) streak[20:30) last_actual[30] at_budget[31]
+//               y = dyn1: hist14[0:14) n_days[16:26) finished[31]
+//               z = episode return (f32 bits), w = budget (int)
+#define D0_T(d) ((d) & 1023u)
+#define D0_USED(d) (((d) >> 10) & 1023u)
+#define D0_STREAK(d) (((d) >> 20) & 1023u)
+#define D0_LAST(d) (((d) >> 30) & 1u)
+#define D0_ATB(d) (((d) >> 31) & 1u)
+#define D1_HIST(d) ((d) & 0x3FFFu)
+#define D1_NDAYS(d) (((d) >> 16) & 1023u)
+#define D1_FIN(d) (((d) >> 31) & 1u)
+
+__device__ __forceinline__ uint32_t pack_d0(uint32_t t, uint32_t used, uint32_t streak, uint32_t last, uint32_t atb) {
+  return (t & 1023u) | ((used > 1023u ? 1023u : used) << 10) | ((streak > 1023u ? 1023u : streak) << 20) |
+         (last << 30) | (atb << 31);
+}
+__device__ __forceinline__ uint32_t pack_d1(uint32_t hist, uint32_t ndays, uint32_t fin) {
+  return (hist & 0x3FFFu) | ((ndays & 1023u) << 16) | (fin << 31);
+}
+
+struct DevTables {
+  const float4 *X;
+  const int32_t *n_days;
+  const int32_t *B0;
+  const float4 *W;
+  const int32_t *fips_to_weather;
+  const int32_t *sim_cnt;
+  int32_t T, S_w, Y, S, n_samples, n_obs;
+};
+
+struct ResetCfg {
+  uint64_t seed;
+  int32_t location;
+  int32_t augment;
+  int32_t budget_kw;
+  int32_t sample_mode;
+  int32_t sticky;
+};
+
+struct w2a_env {
+  DevTables tb;
+  int64_t n;
+  int64_t gid0;
+  const int32_t *slot_obs;  // [32] slot -> obs column (-1 none), in the state header
+  uint4 *cold;
+  uint4 *hot;
+  int32_t *status;
+  ResetCfg autoreset;
+  int has_autoreset;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *a = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a);
+  return code;
+}
+
+// ----------------------------------------------------------------------------------------
+// counter-based RNG (restated in oracle/heatalert_oracle.py: devrng_*)
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t w2a_mix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+__device__ __forceinline__ uint64_t rng_stream(uint64_t seed, uint64_t gid, uint64_t episode) {
+  uint64_t h = w2a_mix64(seed + 0x9E3779B97F4A7C15ull * (gid + 1));
+  return w2a_mix64(h ^ (episode * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull));
+}
+// uniform integer in [0, n): multiply-shift on the high 32 bits of the slot's word
+__device__ __forceinline__ uint32_t rng_bounded(uint64_t stream, uint32_t slot, uint32_t n) {
+  uint64_t u = w2a_mix64(stream + (uint64_t)(slot + 1) * 0x9E3779B97F4A7C15ull) >> 32;
+  return (uint32_t)((u * (uint64_t)n) >> 32);
+}
+
+// ----------------------------------------------------------------------------------------
+// cross-lane helpers (8-lane groups inside a DPP row of 16)
+// ----------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// all-reduce (sum) over the 8 lanes of a group; every lane ends with the total
+__device__ __forceinline__ double group_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  v += dpp_f64<0x141>(v);  // row_half_mirror      : lane -> 7 - lane (other quad of the group)
+  return v;
+}
+
+__device__ __forceinline__ float sigmoid_f32(float z) {
+  // 1/(1+exp(-z)); exp(-z) overflows to +inf for z << 0 which gives exactly 0, and z = -inf
+  // (closed effectiveness gate) also gives exactly 0.
+  float e = __expf(-z);
+  return __frcp_rn(1.0f + e);
+}
+
+// ----------------------------------------------------------------------------------------
+// episode draw shared by the reset kernel and the same-step autoreset (env.py:145-178)
+// ----------------------------------------------------------------------------------------
+struct Episode {
+  uint32_t ep_row, ep_w, ndays;
+  int32_t budget, sticky;
+  uint32_t bad;
+};
+
+__device__ __forceinline__ Episode draw_episode(const DevTables &tb, const ResetCfg &rc, uint64_t gid,
+                                                uint32_t episode_no, int32_t sticky_in) {
+  Episode e;
+  uint64_t st = rng_stream(rc.seed, gid, episode_no);
+  uint32_t bad = 0;
+  uint32_t county = rc.location < 0 ? rng_bounded(st, 0, (uint32_t)tb.S) : (uint32_t)rc.location;
+  if (county >= (uint32_t)tb.S) { county = 0; bad = 1; }
+  uint32_t coef_col = county;
+  if (rc.augment) {
+    int32_t ns = tb.sim_cnt[county];
+    if (ns <= 0) { bad = 1; ns = 1; }
+    coef_col = rng_bounded(st, 1, (uint32_t)ns);  // position inside the filtered list
+  }
+  uint32_t year_i = rng_bounded(st, 2, (uint32_t)tb.Y);
+  uint32_t sample = rng_bounded(st, 3, (uint32_t)tb.n_samples);
+  int32_t cw = tb.fips_to_weather[county];
+  if (cw < 0) { cw = 0; bad = 1; }
+  e.ep_row = (uint32_t)cw * (uint32_t)tb.Y + year_i;
+  e.ep_w = coef_col * (uint32_t)tb.n_samples + sample;
+  int32_t nd = tb.n_days[e.ep_row];
+  if (nd <= 0) { bad = 1; nd = 1; }
+  e.ndays = (uint32_t)nd;
+  int32_t b = (rc.sticky && sticky_in >= 0) ? sticky_in : (rc.budget_kw < 0 ? tb.B0[e.ep_row] : rc.budget_kw);
+  if (b < 0) b = 0;
+  if (rc.sample_mode == W2A_BUDGET_LESS_THAN) {
+    b = (int32_t)rng_bounded(st, 4, (uint32_t)b + 1u);
+  } else if (rc.sample_mode == W2A_BUDGET_CENTERED) {
+    // rng.integers(0.5*b, 1.5*b + 1): NumPy truncates the float bounds
+    int32_t lo = (int32_t)(0.5 * (double)b), hi = (int32_t)(1.5 * (double)b + 1.0);
+    b = lo + (int32_t)rng_bounded(st, 4, (uint32_t)(hi - lo));
+  }
+  e.budget = b;
+  e.sticky = rc.sticky ? b : -1;  // self.budget keeps the (sampled) value (env.py:167-178, Q9)
+  e.bad = bad;
+  return e;
+}
+
+// ----------------------------------------------------------------------------------------
+// observation tile: wave-level transpose through LDS, 16-B coalesced stores
+// ----------------------------------------------------------------------------------------
+// x        : this lane's 4 row floats (slots 4l..4l+3), run-time fields already patched
+// so       : obs column of each of those slots (-1 = not part of the observation)
+// write_me : this env's row must be written (false -> keep what is in memory)
+__device__ __forceinline__ void store_obs_tile(float *__restrict__ obs, float *tile, int64_t wave_env0, int64_t n,
+                                               int n_obs, int lane, int grp, int l, float4 x, int4 so,
+                                               bool write_me) {
+  float *row = tile + grp * n_obs;
+  if (so.x >= 0) row[so.x] = x.x;
+  if (so.y >= 0) row[so.y] = x.y;
+  if (so.z >= 0) row[so.z] = x.z;
+  if (so.w >= 0) row[so.w] = x.w;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool full = (wave_env0 + ENVS_PER_WAVE <= n);
+  const bool all_write = __all(write_me || (wave_env0 + grp >= n));
+  float *dst = obs + wave_env0 * n_obs;
+  if (full && all_write) {
+    const int chunks = (ENVS_PER_WAVE * n_obs) >> 2;  // 8*n_obs floats is a multiple of 4
+    if (lane < chunks) {
+      float4 v = reinterpret_cast<const float4 *>(tile)[lane];
+      reinterpret_cast<float4 *>(dst)[lane] = v;
+    }
+  } else {
+    // ragged tail or some env of the wave keeps its stale row: element-wise, masked
+    const int total = ENVS_PER_WAVE * n_obs;
+    const unsigned long long wm = __ballot(write_me);  // taken before the loop: every lane still active
+    for (int i = lane; i < total; i += 64) {
+      int g = i / n_obs;
+      bool w = (wm >> (g * LANES)) & 1ull;
+      if (w && wave_env0 + g < n) dst[i] = tile[i];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ----------------------------------------------------------------------------------------
+// step kernel
+// ----------------------------------------------------------------------------------------
+struct StepArgs {
+  DevTables tb;
+  const int32_t *slot_obs;
+  uint4 *cold;
+  uint4 *hot;
+  const void *actions;
+  float *obs;
+  float *reward;
+  uint8_t *done;
+  float *last_return;
+  int32_t *status;
+  int64_t n;
+  int64_t gid0;
+  ResetCfg rc;
+  int32_t act_dtype;
+};
+
+template <bool AUTORESET, bool WRITE_OBS>
+__global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l = tid & (LANES - 1);
+  const int grp = lane >> 3;
+  const int64_t wave_env0 = (int64_t)blockIdx.x * ENVS_PER_BLOCK + wave * ENVS_PER_WAVE;
+  const int64_t env = wave_env0 + grp;
+  const bool valid = env < a.n;
+  const int64_t e = valid ? env : (a.n - 1);  // clamp: inactive groups shadow the last env, never store
+
+  const uint4 cold = a.cold[e];
+  const uint4 hot = a.hot[e];
+  int32_t act;
+  if (a.act_dtype == W2A_ACT_I32) act = reinterpret_cast<const int32_t *>(a.actions)[e];
+  else if (a.act_dtype == W2A_ACT_I64) act = (int32_t) reinterpret_cast<const int64_t *>(a.actions)[e];
+  else act = reinterpret_cast<const uint8_t *>(a.actions)[e];
+  uint32_t st_bits = 0;
+  if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
+
+  const uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x);
+  const uint32_t hist = D1_HIST(hot.y), ndays = D1_NDAYS(hot.y);
+  const int32_t budget = (int32_t)hot.w;
+  if (D1_FIN(hot.y)) st_bits |= W2A_ST_STEP_AFTER_DONE;
+
+  // env.py:242-250  budget gate, history
+  const uint32_t atb = ((int32_t)used == budget) ? 1u : 0u;
+  const uint32_t actual = (act == 1 && atb) ? 0u : (uint32_t)act;
+  const uint32_t used2 = used + actual;
+  const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+
+  // gathers: feature row of day t (pre-increment, Q6) and the env's two coefficient rows
+  const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+  const float4 *xp = a.tb.X + ((size_t)t * rows_per_day + cold.x) * (ROWF / 4) + l;
+  const float4 *wp = a.tb.W + (size_t)cold.y * (2 * ROWF / 4) + l;
+  float4 x = *xp;
+  const float4 wb = wp[0];
+  const float4 we = wp[ROWF / 4];
+  const int4 so = reinterpret_cast<const int4 *>(a.slot_obs)[l];
+
+  // env.py:190-193 run-time fields live in slots 24..27 = lane 6
+  if (l == 6) {
+    x.x = (t > 0) ? (float)actual : 0.0f;          // alert_lag1: today's action for t>0 (Q3)
+    x.y = (float)streak;                           // streak before today's action (Q4)
+    x.z = (float)(budget - (int32_t)used2);        // remaining_budget
+    x.w = (float)__popc(hist2);                    // agent's 14-day count ('alert_2wks', Q1)
+  }
+  // env.py:207-217: two 28-term dot products, fp64 accumulation
+  double zb = (double)x.x * (double)wb.x;
+  zb = fma((double)x.y, (double)wb.y, zb);
+  zb = fma((double)x.z, (double)wb.z, zb);
+  zb = fma((double)x.w, (double)wb.w, zb);
+  double ze = (double)x.x * (double)we.x;
+  ze = fma((double)x.y, (double)we.y, ze);
+  ze = fma((double)x.z, (double)we.z, ze);
+  ze = fma((double)x.w, (double)we.w, ze);
+  // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 (lane 7, .z) holds a copy of heat_qi with a
+  // zero coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
+  if (l == 7 && !(x.z > 0.5f)) ze = -__builtin_inf();
+  zb = group_sum(zb);
+  ze = group_sum(ze);
+  const float base = sigmoid_f32((float)zb);
+  const float eff = sigmoid_f32((float)ze);
+  // env.py:221
+  const float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+
+  const bool done = (t + 1 >= ndays);  // env.py:256
+  uint32_t t2 = t, streak2 = streak, fin = 0;
+  if (!done) {
+    t2 = t + 1;
+    streak2 = actual ? streak + 1 : 0;  // env.py:260
+  } else {
+    fin = 1;
+  }
+  float ret = __uint_as_float(hot.z) + r;
+
+  uint4 hot2 = make_uint4(pack_d0(t2, used2, streak2, actual, atb), pack_d1(hist2, ndays, fin),
+                          __float_as_uint(ret), (uint32_t)budget);
+  uint4 cold2 = cold;
+  bool write_row = !done;
+  if (done && valid && l == 0 && a.last_return) a.last_return[e] = ret;
+  if (AUTORESET) {
+    if (done) {
+      // same-step autoreset: draw the next episode, emit its first observation (env.py:162-181)
+      Episode ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
+      if (ep.bad) st_bits |= W2A_ST_BAD_EPISODE;
+      cold2 = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
+      hot2 = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
+      if (WRITE_OBS) {
+        x = a.tb.X[(size_t)ep.ep_row * (ROWF / 4) + l];
+        if (l == 6) x = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+      }
+      write_row = true;
+    }
+  }
+  if (valid && l == 0) {
+    a.hot[e] = hot2;
+    a.reward[e] = r;
+    a.done[e] = done ? 1 : 0;
+    if (AUTORESET && done) a.cold[e] = cold2;
+  }
+  if (st_bits && valid && l == 0) atomicOr(a.status, (int)st_bits);
+  if (WRITE_OBS) {
+    store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, l, x, so, write_row);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// reset kernels (same 8-lane geometry so the observation tile code is shared)
+// ----------------------------------------------------------------------------------------
+struct ResetArgs {
+  DevTables tb;
+  const int32_t *slot_obs;
+  uint4 *cold;
+  uint4 *hot;
+  const int32_t *county_w, *year_i, *coef_col, *sample, *budget;  // host-tuple mode
+  const uint8_t *mask;
+  float *obs;
+  int32_t *status;
+  int64_t n;
+  int64_t gid0;
+  ResetCfg rc;
+  int32_t from_tuples;
+  int32_t first;  // 1: state is uninitialised (create): sticky = -1, episode_no = 0
+};
+
+__global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l = tid & (LANES - 1);
+  const int grp = lane >> 3;
+  const int64_t wave_env0 = (int64_t)blockIdx.x * ENVS_PER_BLOCK + wave * ENVS_PER_WAVE;
+  const int64_t env = wave_env0 + grp;
+  const bool valid = env < a.n;
+  const int64_t e = valid ? env : (a.n - 1);
+  const bool sel = a.mask ? (a.mask[e] != 0) : true;
+  uint4 cold = a.cold[e];
+  uint32_t bad = 0;
+  Episode ep;
+  if (a.from_tuples) {
+    int32_t cw = a.county_w[e], yi = a.year_i[e], cc = a.coef_col[e], sm = a.sample[e];
+    if (cw < 0 || cw >= a.tb.S_w) { cw = 0; bad = 1; }
+    if (yi < 0 || yi >= a.tb.Y) { yi = 0; bad = 1; }
+    if (cc < 0 || cc >= a.tb.S) { cc = 0; bad = 1; }
+    if (sm < 0 || sm >= a.tb.n_samples) { sm = 0; bad = 1; }
+    ep.ep_row = (uint32_t)cw * (uint32_t)a.tb.Y + (uint32_t)yi;
+    ep.ep_w = (uint32_t)cc * (uint32_t)a.tb.n_samples + (uint32_t)sm;
+    int32_t nd = a.tb.n_days[ep.ep_row];
+    if (nd <= 0) { nd = 1; bad = 1; }
+    ep.ndays = (uint32_t)nd;
+    ep.budget = a.budget ? a.budget[e] : a.tb.B0[ep.ep_row];
+    ep.sticky = (int32_t)cold.z;
+  } else {
+    ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
+    bad = ep.bad;
+  }
+  float4 x = a.tb.X[(size_t)ep.ep_row * (ROWF / 4) + l];  // day 0
+  if (l == 6) x = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+  const int4 so = reinterpret_cast<const int4 *>(a.slot_obs)[l];
+  if (valid && sel && l == 0) {
+    a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
+    a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
+    if (bad) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
+  }
+  if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, l, x, so, sel);
+}
+
+__global__ void k_init_state(uint4 *cold, uint4 *hot, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    cold[i] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);  // sticky = -1, episode_no = -1 (first reset -> 0)
+    hot[i] = make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u);
+  }
+}
+
+__global__ void k_get_state(const uint4 *cold, const uint4 *hot, int64_t n, int32_t Y, int32_t n_samples,
+                            w2a_state_view v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4 c = cold[i], h = hot[i];
+  if (v.t) v.t[i] = (int32_t)D0_T(h.x);
+  if (v.used) v.used[i] = (int32_t)D0_USED(h.x);
+  if (v.streak) v.streak[i] = (int32_t)D0_STREAK(h.x);
+  if (v.last_actual) v.last_actual[i] = (int32_t)D0_LAST(h.x);
+  if (v.at_budget) v.at_budget[i] = (int32_t)D0_ATB(h.x);
+  if (v.hist14) v.hist14[i] = (int32_t)D1_HIST(h.y);
+  if (v.n_days) v.n_days[i] = (int32_t)D1_NDAYS(h.y);
+  if (v.budget) v.budget[i] = (int32_t)h.w;
+  if (v.episode_return) v.episode_return[i] = __uint_as_float(h.z);
+  if (v.county_w) v.county_w[i] = (int32_t)(c.x / (uint32_t)Y);
+  if (v.year_i) v.year_i[i] = (int32_t)(c.x % (uint32_t)Y);
+  if (v.coef_col) v.coef_col[i] = (int32_t)(c.y / (uint32_t)n_samples);
+  if (v.sample) v.sample[i] = (int32_t)(c.y % (uint32_t)n_samples);
+  if (v.sticky_budget) v.sticky_budget[i] = (int32_t)c.z;
+  if (v.episode_no) v.episode_no[i] = (int32_t)c.w;
+}
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                   \
+  do {                                                                  \
+    hipError_t _e = (expr);                                             \
+    if (_e != hipSuccess) return fail(W2A_ERR_HIP, #expr ": %s", hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" {
+
+int w2a_abi_version(void) { return W2A_ABI_VERSION; }
+const char *w2a_last_error(void) { return g_err; }
+
+size_t w2a_state_bytes(int64_t num_envs) {
+  if (num_envs <= 0) return 0;
+  size_t b = HDR_BYTES + (size_t)num_envs * 32;
+  return (b + 255) & ~(size_t)255;
+}
+
+int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *state, size_t state_bytes,
+               int32_t *status, w2a_env **out) {
+  if (!t || !state || !status || !out) return fail(W2A_ERR_ARG, "w2a_create: NULL argument");
+  if (num_envs <= 0 || env_gid0 < 0) return fail(W2A_ERR_ARG, "w2a_create: num_envs must be > 0 and env_gid0 >= 0");
+  if (!t->X || !t->n_days || !t->B0 || !t->W || !t->fips_to_weather || !t->sim_cnt)
+    return fail(W2A_ERR_ARG, "w2a_create: NULL table pointer");
+  if (t->T <= 0 || t->T > 1023 || t->S_w <= 0 || t->Y <= 0 || t->S <= 0 || t->n_samples <= 0)
+    return fail(W2A_ERR_SCHEMA, "w2a_create: table dims out of range (need 0 < T <= 1023, positive S_w, Y, S, n_samples)");
+  if ((int64_t)t->S_w * t->Y > 0x7FFFFFFFll / 2 || (int64_t)t->S * t->n_samples > 0x7FFFFFFFll / 2)
+    return fail(W2A_ERR_SCHEMA, "w2a_create: table too large for 32-bit row indices");
+  if (t->n_obs <= 0 || t->n_obs > W2A_ROW_FLOATS) return fail(W2A_ERR_SCHEMA, "w2a_create: n_obs must be in 1..32");
+  if (state_bytes < w2a_state_bytes(num_envs)) return fail(W2A_ERR_STATE, "w2a_create: state buffer too small");
+  if (((uintptr_t)state & 255) || ((uintptr_t)t->X & 15) || ((uintptr_t)t->W & 15))
+    return fail(W2A_ERR_STATE, "w2a_create: state must be 256-B aligned, X and W 16-B aligned");
+  int32_t slot_obs[ROWF];
+  for (int i = 0; i < ROWF; ++i) slot_obs[i] = -1;
+  for (int j = 0; j < t->n_obs; ++j) {
+    int s = t->obs_slot[j];
+    if (s < 0 || s >= ROWF || slot_obs[s] != -1) return fail(W2A_ERR_SCHEMA, "w2a_create: obs_slot is not an injective map into 0..31");
+    slot_obs[s] = j;
+  }
+  w2a_env *h = new w2a_env();
+  h->tb.X = reinterpret_cast<const float4 *>(t->X);
+  h->tb.n_days = t->n_days;
+  h->tb.B0 = t->B0;
+  h->tb.W = reinterpret_cast<const float4 *>(t->W);
+  h->tb.fips_to_weather = t->fips_to_weather;
+  h->tb.sim_cnt = t->sim_cnt;
+  h->tb.T = t->T; h->tb.S_w = t->S_w; h->tb.Y = t->Y; h->tb.S = t->S; h->tb.n_samples = t->n_samples;
+  h->tb.n_obs = t->n_obs;
+  h->n = num_envs;
+  h->gid0 = env_gid0;
+  h->slot_obs = reinterpret_cast<const int32_t *>(state);
+  h->cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
+  h->hot = h->cold + num_envs;
+  h->status = status;
+  h->has_autoreset = 0;
+  hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
+  hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
+  if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: header upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
+  int64_t blocks = (num_envs + 255) / 256;
+  hipLaunchKernelGGL(k_init_state, dim3((unsigned)blocks), dim3(256), 0, 0, h->cold, h->hot, num_envs);
+  hipError_t e3 = hipDeviceSynchronize();
+  if (e3 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernel failed: %s", hipGetErrorString(e3)); }
+  *out = h;
+  return W2A_OK;
+}
+
+void w2a_destroy(w2a_env *env) { delete env; }
+
+static unsigned grid_for(int64_t n) { return (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK); }
+
+static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
+  a.tb = env->tb; a.slot_obs = env->slot_obs; a.cold = env->cold; a.hot = env->hot;
+  a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
+  if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
+  hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, const int32_t *coef_col,
+              const int32_t *sample, const int32_t *budget, const uint8_t *mask, float *obs, void *stream) {
+  if (!env || !county_w || !year_i || !coef_col || !sample) return fail(W2A_ERR_ARG, "w2a_reset: NULL argument");
+  ResetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.county_w = county_w; a.year_i = year_i; a.coef_col = coef_col; a.sample = sample; a.budget = budget;
+  a.mask = mask; a.obs = obs; a.from_tuples = 1;
+  return launch_reset(env, a, stream);
+}
+
+static int fill_cfg(const w2a_env *env, ResetCfg &rc, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                    int mode, int sticky) {
+  if (location >= env->tb.S) return fail(W2A_ERR_ARG, "reset: location index outside fips_list");
+  if (mode < W2A_BUDGET_FIXED || mode > W2A_BUDGET_CENTERED) return fail(W2A_ERR_ARG, "reset: bad sample_budget_mode");
+  rc.seed = seed; rc.location = location; rc.augment = augment ? 1 : 0; rc.budget_kw = budget_kw;
+  rc.sample_mode = mode; rc.sticky = sticky ? 1 : 0;
+  return W2A_OK;
+}
+
+int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                         int sample_budget_mode, int sticky, const uint8_t *mask, float *obs, void *stream) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_reset_device_rng: NULL handle");
+  ResetArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
+  if (rc) return rc;
+  a.mask = mask; a.obs = obs; a.from_tuples = 0;
+  return launch_reset(env, a, stream);
+}
+
+int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                      int sample_budget_mode, int sticky) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_set_autoreset: NULL handle");
+  int rc = fill_cfg(env, env->autoreset, seed, location, augment, budget_kw, sample_budget_mode, sticky);
+  if (rc) return rc;
+  env->has_autoreset = 1;
+  return W2A_OK;
+}
+
+int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, float *reward, uint8_t *done,
+             float *last_return, int flags, void *stream) {
+  if (!env || !actions || !reward || !done) return fail(W2A_ERR_ARG, "w2a_step: NULL argument");
+  if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_step: bad action_dtype");
+  const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
+  const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
+  if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
+  if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
+  if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
+  StepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tb = env->tb; a.slot_obs = env->slot_obs; a.cold = env->cold; a.hot = env->hot;
+  a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
+  a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
+  dim3 grid(grid_for(env->n)), block(BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+  if (autoreset) {
+    if (no_obs) hipLaunchKernelGGL((k_step<true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_step<true, true>), grid, block, 0, s, a);
+  } else {
+    if (no_obs) hipLaunchKernelGGL((k_step<false, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_step<false, true>), grid, block, 0, s, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
+  if (!env || !view) return fail(W2A_ERR_ARG, "w2a_get_state: NULL argument");
+  int64_t blocks = (env->n + 255) / 256;
+  hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->cold, env->hot,
+                     env->n, env->tb.Y, env->tb.n_samples, *view);
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_read_status(w2a_env *env, int32_t *status_out, void *stream) {
+  if (!env || !status_out) return fail(W2A_ERR_ARG, "w2a_read_status: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(status_out, env->status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemsetAsync(env->status, 0, sizeof(int32_t), s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return W2A_OK;
+}
+
+}  // extern "C"

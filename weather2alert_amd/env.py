@@ -1,0 +1,463 @@
+"""Vectorised, MI355X-resident HeatAlertEnv with the reference's reset()/step() surface.
+
+``HeatAlertVecEnv`` steps ``num_envs`` independent copies of the reference's
+``weather2alert.env.HeatAlertEnv`` (``/root/reference/src/weather2alert/env.py``) inside
+hand-written gfx950 kernels (``csrc/w2a_kernels.hip`` through the C ABI of
+``include/w2a.h``). ``HeatAlertEnv`` is the ``num_envs=1`` drop-in with the reference's
+exact constructor / ``reset`` / ``step`` signatures and NumPy-seed parity.
+
+All reference quirks listed in SURVEY.md §3.3 (Q1-Q12) are reproduced; there is no CPU
+fallback -- constructing an env without a ROCm device or without libw2a.so raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Literal
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .spaces import Box, Discrete
+from .tables import CompiledTables, DeviceTables, compile_from_files
+
+_ACT_CODES = {torch.int32: _ffi.ACT_I32, torch.int64: _ffi.ACT_I64, torch.uint8: _ffi.ACT_U8,
+              torch.bool: _ffi.ACT_U8}
+_BUDGET_MODES = {"less_than": _ffi.BUDGET_LESS_THAN, "centered": _ffi.BUDGET_CENTERED}
+
+
+class HeatAlertVecEnv:
+    """``num_envs`` heat-alert environments stepped in lock step on one MI355X.
+
+    Constructor keeps the reference's keyword arguments (env.py:20-29) and adds:
+
+    num_envs, device     batch size and ROCm device
+    seed_mode            "device": every draw of reset() comes from the counter-based device RNG
+                         keyed by (seed, global env id, episode number) -- same distributions as
+                         the reference, not the same stream; "numpy_parity": the host replays
+                         NumPy's Generator call sequence of env.py:145-177 per env (env i is
+                         seeded with seed+i), bit-identical episode tuples to the reference.
+    autoreset            "same_step" (finished envs restart inside the same step() call and the
+                         returned observation is the new episode's first one; the finished
+                         episode's return is in info["final_return"]) or "disabled".
+    tables               pre-compiled CompiledTables (skips file loading)
+    env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
+    """
+
+    metadata = {"autoreset_mode": "same_step"}
+
+    def __init__(
+        self,
+        num_envs: int = 1,
+        weights: str = "nn_full_medicare_all",
+        years: list | None = None,
+        fips_list: list | None = None,  # ignored, like the reference (overwritten at env.py:75)
+        similar_climate_counties: bool = False,
+        budget: int | None = None,
+        data_dir: str | None = None,
+        split: str = "65k",
+        device: str | torch.device = "cuda:0",
+        seed_mode: Literal["device", "numpy_parity"] = "device",
+        autoreset: Literal["same_step", "disabled"] = "same_step",
+        tables: CompiledTables | DeviceTables | None = None,
+        env_gid0: int = 0,
+        write_obs: bool = True,
+    ):
+        self._lib = _ffi.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("HeatAlertVecEnv needs a ROCm GPU (device='cuda:N'); there is no CPU fallback")
+        if num_envs <= 0:
+            raise ValueError("num_envs must be positive")
+        if seed_mode not in ("device", "numpy_parity"):
+            raise ValueError(f"seed_mode {seed_mode!r}")
+        if autoreset not in ("same_step", "disabled"):
+            raise ValueError(f"autoreset {autoreset!r}")
+        self.num_envs = int(num_envs)
+        self.similar_climate_counties = bool(similar_climate_counties)
+        self.seed_mode = seed_mode
+        self.autoreset = autoreset
+        self.env_gid0 = int(env_gid0)
+        self.write_obs = bool(write_obs)
+        self._ctor_budget = budget
+        if isinstance(tables, DeviceTables):
+            self.dtables = tables
+        else:
+            ct = tables if tables is not None else compile_from_files(data_dir, weights, split, years)
+            self.dtables = DeviceTables(ct, self.device)
+        ct = self.ct = self.dtables.ct
+        self.fips_list = ct.fips_list
+        self.valid_years = ct.years
+        self.n_samples = ct.n_samples
+        self.feature_names = ct.feature_names
+        self._fips_pos = {f: i for i, f in enumerate(ct.fips_list)}
+        # Q12: the true observation width (the reference declares len(columns)+2 = 33, env.py:88)
+        self.single_observation_space = Box(-np.inf, np.inf, (ct.n_obs,), np.float32)
+        self.single_action_space = Discrete(2)  # env.py:95
+        self.observation_space = Box(-np.inf, np.inf, (self.num_envs, ct.n_obs), np.float32)
+        self.action_space = self.single_action_space
+
+        n, dev = self.num_envs, self.device
+        with torch.cuda.device(dev):
+            nbytes = self._lib.w2a_state_bytes(n)
+            self._state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._obs = torch.zeros((n, ct.n_obs), dtype=torch.float32, device=dev)
+            self._reward = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self._final_return = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._truncated = torch.zeros(n, dtype=torch.bool, device=dev)
+            h = C.c_void_p()
+            _ffi.check(self._lib.w2a_create(C.byref(self.dtables.struct), n, self.env_gid0, self._state.data_ptr(),
+                                            nbytes, self._status.data_ptr(), C.byref(h)), "w2a_create")
+        self._h = h
+        self._sticky = [budget] * n  # host mirror of self.budget per env (numpy_parity mode, Q9)
+        self._needs_reset = True
+        self._flags = 0
+        self._last_opts: dict = {}
+        self._episode_seed = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self._lib.w2a_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def check_status(self) -> int:
+        """Synchronise and raise if a kernel flagged bad inputs since the last call."""
+        out = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.w2a_read_status(self._h, C.byref(out), self._stream()), "w2a_read_status")
+        bits = out.value
+        if bits & _ffi.ST_BAD_EPISODE:
+            raise KeyError("reset: an episode tuple is out of range or has no data "
+                           "(reference: KeyError at env.py:127 / ValueError at env.py:121)")
+        if bits & _ffi.ST_BAD_ACTION:
+            raise ValueError("step: actions must be 0 or 1 (action_space = Discrete(2))")
+        return bits
+
+    def state(self) -> dict[str, torch.Tensor]:
+        """Decoded per-env integer state (device tensors)."""
+        v = _ffi.StateView()
+        out = {}
+        for k in _ffi.STATE_FIELDS:
+            dt = torch.float32 if k == "episode_return" else torch.int32
+            out[k] = torch.empty(self.num_envs, dtype=dt, device=self.device)
+            setattr(v, k, out[k].data_ptr())
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.w2a_get_state(self._h, C.byref(v), self._stream()), "w2a_get_state")
+        return out
+
+    # ------------------------------------------------------------------ reset
+    def _opt(self, options, key, default):
+        v = None if options is None else options.get(key)
+        return default if v is None else v
+
+    def reset(self, seed: int | list | None = None, options: dict | None = None):
+        """Gymnasium VectorEnv.reset. ``options`` carries the reference's reset kwargs
+        (env.py:133-141): location, similar_climate_counties, budget, sample_budget,
+        sample_budget_type -- scalars, or per-env sequences in numpy_parity mode -- plus
+        "episodes": dict of int arrays (county_w, year_i, coef_col, sample, budget) to inject
+        episode tuples directly, and "mask": bool[num_envs] to reset a subset."""
+        options = dict(options or {})
+        mask = options.get("mask")
+        mask_t = None
+        if mask is not None:
+            mask_t = torch.as_tensor(np.asarray(mask), dtype=torch.uint8, device=self.device)
+        obs_ptr = self._obs.data_ptr() if self.write_obs else None
+        self._last_opts = {k: v for k, v in options.items() if k not in ("mask", "episodes")}
+        if "episodes" in options:
+            self._reset_tuples(options["episodes"], mask_t, obs_ptr)
+        elif self.seed_mode == "numpy_parity":
+            self._reset_numpy_parity(seed, options, mask, mask_t, obs_ptr)
+        else:
+            self._reset_device(seed, options, mask_t, obs_ptr)
+        self._needs_reset = False
+        return self._obs, self._info()
+
+    def _reset_tuples(self, ep: dict, mask_t, obs_ptr):
+        ct, n = self.ct, self.num_envs
+        arrs = {}
+        for k in ("county_w", "year_i", "coef_col", "sample"):
+            a = np.broadcast_to(np.asarray(ep[k], dtype=np.int64), (n,))
+            arrs[k] = a
+        lim = {"county_w": ct.S_w, "year_i": ct.Y, "coef_col": ct.S, "sample": ct.n_samples}
+        sel = np.ones(n, bool) if mask_t is None else mask_t.cpu().numpy().astype(bool)
+        for k, a in arrs.items():
+            if ((a[sel] < 0) | (a[sel] >= lim[k])).any():
+                raise KeyError(f"reset: {k} outside [0, {lim[k]})")
+        rows = arrs["county_w"] * ct.Y + arrs["year_i"]
+        if (ct.n_days[rows[sel]] <= 0).any():
+            raise KeyError("reset: (county, year) has no data (reference: KeyError at env.py:127)")
+        if ep.get("budget") is None:
+            bud = ct.B0[rows].astype(np.int64)
+        else:
+            bud = np.broadcast_to(np.asarray(ep["budget"], dtype=np.int64), (n,))
+        dev = self.device
+        t = {k: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=dev) for k, a in arrs.items()}
+        tb = torch.as_tensor(np.ascontiguousarray(bud), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _ffi.check(self._lib.w2a_reset(self._h, t["county_w"].data_ptr(), t["year_i"].data_ptr(),
+                                           t["coef_col"].data_ptr(), t["sample"].data_ptr(), tb.data_ptr(),
+                                           None if mask_t is None else mask_t.data_ptr(), obs_ptr, self._stream()),
+                       "w2a_reset")
+        self._keep = (t, tb, mask_t)  # keep inputs alive until the async launch has consumed them
+
+    def _per_env(self, v, i):
+        if isinstance(v, (list, tuple, np.ndarray)):
+            return v[i]
+        return v
+
+    def _reset_numpy_parity(self, seed, options, mask, mask_t, obs_ptr):
+        """Host replay of env.py:143-178 per env with NumPy's own Generator."""
+        ct, n = self.ct, self.num_envs
+        loc_o = options.get("location")
+        aug_o = self._opt(options, "similar_climate_counties", self.similar_climate_counties)
+        bud_o = options.get("budget")
+        sb_o = self._opt(options, "sample_budget", False)
+        sbt_o = self._opt(options, "sample_budget_type", "less_than")
+        cw, yi, cc, sm, bd = (np.zeros(n, np.int64) for _ in range(5))
+        self._info_location = getattr(self, "_info_location", [None] * n)
+        sel = np.ones(n, bool) if mask is None else np.asarray(mask, bool)
+        for i in range(n):
+            if not sel[i]:
+                continue
+            if seed is None:
+                s = np.random.randint(0, 10000)  # env.py:143-144
+            elif isinstance(seed, (list, tuple, np.ndarray)):
+                s = int(seed[i])
+            else:
+                s = int(seed) + i
+            rng = np.random.default_rng(s)
+            location = self._per_env(loc_o, i)
+            if location is None:
+                location = str(rng.choice(ct.fips_list))  # env.py:151-152
+            if location not in self._fips_pos:
+                raise ValueError(f"{location!r} is not in list")  # env.py:121 list.index
+            county = self._fips_pos[location]
+            if bool(self._per_env(aug_o, i)):
+                ns = int(ct.sim_cnt[county])
+                if ns == 0:
+                    raise KeyError(location)  # confounders.loc[fips] (datautils.py:123)
+                li = int(rng.choice(range(ns)))  # env.py:117
+                self._info_location[i] = ct.fips_list[int(ct.similar_list(county)[li])]
+            else:
+                li = county
+                self._info_location[i] = location
+            year = int(rng.choice(ct.years))  # env.py:125
+            w = int(ct.fips_to_weather[county])
+            y_i = ct.years.index(year)
+            if w < 0 or ct.n_days[w * ct.Y + y_i] <= 0:
+                raise KeyError((location, year))  # env.py:127
+            ci = int(rng.integers(0, ct.n_samples))  # env.py:160
+            b = self._sticky[i]
+            if b is None:  # env.py:167-170
+                bk = self._per_env(bud_o, i)
+                b = int(ct.B0[w * ct.Y + y_i]) if bk is None else int(bk)
+            if bool(self._per_env(sb_o, i)):  # env.py:172-177
+                typ = self._per_env(sbt_o, i)
+                if typ == "less_than":
+                    b = int(rng.integers(0, b + 1))
+                elif typ == "centered":
+                    b = int(rng.integers(0.5 * b, 1.5 * b + 1))
+            self._sticky[i] = b
+            cw[i], yi[i], cc[i], sm[i], bd[i] = w, y_i, li, ci, b
+        self._reset_tuples(dict(county_w=cw, year_i=yi, coef_col=cc, sample=sm, budget=bd), mask_t, obs_ptr)
+
+    def _device_cfg(self, seed, options):
+        loc = options.get("location")
+        if loc is None:
+            loc_i = -1
+        else:
+            if loc not in self._fips_pos:
+                raise ValueError(f"{loc!r} is not in list")
+            loc_i = self._fips_pos[loc]
+            if self.ct.fips_to_weather[loc_i] < 0:
+                raise KeyError(loc)
+        aug = bool(self._opt(options, "similar_climate_counties", self.similar_climate_counties))
+        bk = self._ctor_budget if self._ctor_budget is not None else options.get("budget")
+        mode = _ffi.BUDGET_FIXED
+        if self._opt(options, "sample_budget", False):
+            typ = self._opt(options, "sample_budget_type", "less_than")
+            if typ not in _BUDGET_MODES:
+                raise ValueError(f"sample_budget_type {typ!r}")
+            mode = _BUDGET_MODES[typ]
+        if seed is None:
+            seed = int(np.random.randint(0, 2**31 - 1))
+        return int(seed) & (2**64 - 1), loc_i, int(aug), -1 if bk is None else int(bk), mode, 1
+
+    def _reset_device(self, seed, options, mask_t, obs_ptr):
+        ct = self.ct
+        if (ct.fips_to_weather < 0).any() or (ct.n_days <= 0).any():
+            raise KeyError("seed_mode='device' needs state tables for every fips_list county and year "
+                           "(the reference raises KeyError at env.py:127 when it draws a missing pair)")
+        cfg = self._device_cfg(seed, options)
+        if cfg[2] and (ct.sim_cnt <= 0).any() and cfg[1] < 0:
+            raise KeyError("a fips_list county is missing from the confounders table (datautils.py:123)")
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.w2a_reset_device_rng(self._h, *cfg, None if mask_t is None else mask_t.data_ptr(),
+                                                      obs_ptr, self._stream()), "w2a_reset_device_rng")
+            _ffi.check(self._lib.w2a_set_autoreset(self._h, *cfg), "w2a_set_autoreset")
+        self._keep = (mask_t,)
+
+    # ------------------------------------------------------------------ step
+    def step(self, actions):
+        """Gymnasium VectorEnv.step: (obs, reward, terminated, truncated, info), all device
+        tensors that are reused by the next call (clone them to keep a copy)."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before step()")
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        elif actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dtype not in _ACT_CODES:
+            actions = actions.to(torch.int32)
+        if actions.numel() != self.num_envs:
+            raise ValueError(f"expected {self.num_envs} actions, got {actions.numel()}")
+        if not actions.is_contiguous():
+            actions = actions.contiguous()
+        flags = 0 if self.write_obs else _ffi.STEP_NO_OBS
+        dev_auto = self.autoreset == "same_step" and self.seed_mode == "device"
+        if dev_auto:
+            flags |= _ffi.STEP_AUTORESET
+        rc = self._lib.w2a_step(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype],
+                                self._obs.data_ptr() if self.write_obs else None, self._reward.data_ptr(),
+                                self._done.data_ptr(), self._final_return.data_ptr(), flags, self._stream())
+        if rc != 0:
+            _ffi.check(rc, "w2a_step")
+        self._keep_act = actions
+        done = self._done.view(torch.bool)
+        if self.autoreset == "same_step" and not dev_auto:
+            d = done.cpu().numpy()
+            if d.any():  # host-side autoreset (numpy_parity): fresh global-RNG seeds like reset(seed=None)
+                self._reset_numpy_parity(None, self._last_opts, d, torch.as_tensor(d.astype(np.uint8),
+                                         device=self.device), self._obs.data_ptr() if self.write_obs else None)
+        return self._obs, self._reward, done, self._truncated, self._info()
+
+    def _info(self):
+        return _LazyInfo(self)
+
+
+class _LazyInfo(dict):
+    """info dict whose entries are fetched from the device on first access (env.py:228-236).
+    Keys: remaining_budget, at_budget, location_index (coefficient column), county_w, year,
+    feature_names, final_return."""
+
+    _KEYS = ("remaining_budget", "at_budget", "location_index", "county_w", "year", "feature_names",
+             "final_return", "t")
+
+    def __init__(self, env: HeatAlertVecEnv):
+        super().__init__()
+        self._env = env
+
+    def _fill(self):
+        if not super().__len__():
+            e = self._env
+            st = e.state()
+            years = torch.as_tensor(e.ct.years, dtype=torch.int32, device=e.device)
+            super().update(
+                remaining_budget=st["budget"] - st["used"], at_budget=st["at_budget"].bool(),
+                location_index=st["coef_col"], county_w=st["county_w"], year=years[st["year_i"].long()],
+                feature_names=e.feature_names, final_return=e._final_return, t=st["t"])
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        return len(self._KEYS)
+
+
+class HeatAlertEnv:
+    """Drop-in for ``weather2alert.env.HeatAlertEnv`` (env.py:17-262): same constructor,
+    ``reset(location, similar_climate_counties, seed, budget, sample_budget, sample_budget_type)``
+    and ``step(action) -> (obs, reward, done, False, info)``; one env on the GPU, episode draws
+    replayed from NumPy's Generator so identical seeds give identical episodes.
+
+    Differences by construction: observations are float32 arrays of the true width 29 with
+    ``alert`` as 0/1 and ``significance`` as a category code (the reference returns an object
+    array mixing floats, ints, bools and strings)."""
+
+    def __init__(self, weights: str = "nn_full_medicare_all", years: list | None = None,
+                 fips_list: list | None = None, similar_climate_counties: bool = False, budget: int | None = None,
+                 data_dir: str | None = None, split: str = "65k", device: str = "cuda:0",
+                 tables: CompiledTables | DeviceTables | None = None):
+        self._v = HeatAlertVecEnv(1, weights, years, fips_list, similar_climate_counties, budget, data_dir, split,
+                                  device, seed_mode="numpy_parity", autoreset="disabled", tables=tables)
+        ct = self._v.ct
+        self.fips_list, self.valid_years, self.n_samples = ct.fips_list, ct.years, ct.n_samples
+        self.similar_climate_counties = similar_climate_counties
+        self.observation_space = self._v.single_observation_space
+        self.action_space = self._v.single_action_space
+        self.feat_names = ct.feature_names
+
+    @property
+    def budget(self):
+        return self._v._sticky[0]
+
+    def _sync_state(self):
+        st = {k: v.cpu().numpy()[0] for k, v in self._v.state().items()}
+        ct = self._v.ct
+        self.t = int(st["t"])
+        self.alert_streak = int(st["streak"])
+        self.coef_index = int(st["sample"])
+        self.location_index = int(st["coef_col"])
+        self.remaining_budget = int(st["budget"] - st["used"])
+        self.at_budget = bool(st["at_budget"])
+        self.n_days = int(st["n_days"])
+        self.location = self._v._info_location[0]
+        self.ep_index = ct.fips_weather[int(st["county_w"])] + "_" + str(ct.years[int(st["year_i"])])
+        return st
+
+    def _get_info(self):
+        return {"episode_index": self.ep_index, "remaining_budget": self.remaining_budget,
+                "at_budget": self.at_budget, "feature_names": self.feat_names, "location": self.location,
+                "location_index": self.location_index}
+
+    def reset(self, location: str | None = None, similar_climate_counties: bool | None = None,
+              seed: int | None = None, budget: int | None = None, sample_budget: bool = False,
+              sample_budget_type: Literal["less_than", "centered"] = "less_than"):
+        if seed is None:
+            seed = np.random.randint(0, 10000)
+        obs, _ = self._v.reset(seed=[seed], options=dict(
+            location=location, similar_climate_counties=similar_climate_counties, budget=budget,
+            sample_budget=sample_budget, sample_budget_type=sample_budget_type))
+        self._v.check_status()
+        self._sync_state()
+        self.observation = obs[0].cpu().numpy().copy()
+        return self.observation, self._get_info()
+
+    def step(self, action: int):
+        obs, r, done, _, _ = self._v.step(torch.tensor([int(action)], dtype=torch.int32, device=self._v.device))
+        self._v.check_status()
+        self._sync_state()
+        self.observation = obs[0].cpu().numpy().copy()
+        return self.observation, float(r[0].item()), bool(done[0].item()), False, self._get_info()
+
+    def close(self):
+        self._v.close()
