@@ -217,6 +217,11 @@ def main():
         "declared_obs_shape": list(e0.observation_space.shape),
     }
     pack(rec, os.path.join(HERE, "mini_traj.npz"), extra)
+    # the same data set compiled to dense tables: the GPU box has no parquet engine, so the
+    # -m gpu tests load this instead of the parquet files (tests/test_tables.py proves they agree)
+    from weather2alert_amd import tables as _tables
+
+    _tables.compile_from_files(mini_root, "linear").save_npz(os.path.join(HERE, "mini_compiled.npz"))
 
     # ---------------- full-size anchors (tables not committed) ----------------
     full_root = os.path.join(tmp, "full")

@@ -31,8 +31,10 @@ def mini(golden_dir, mini_root, dev):
 
     d = dict(np.load(os.path.join(golden_dir, "mini_traj.npz")))
     meta = json.loads(str(d["meta_json"]))
-    ct = tables.compile_from_files(mini_root, "linear")
-    return d, meta, ct, DeviceTables(ct, dev), O.RefData.from_files(mini_root, "linear")
+    # dense tables compiled from tests/golden/mini/*.parquet in the build container (the GPU box has no
+    # parquet engine); tests/test_tables.py::test_compiled_fixture_is_current pins it to the files
+    ct = tables.CompiledTables.load_npz(os.path.join(golden_dir, "mini_compiled.npz"))
+    return d, meta, ct, DeviceTables(ct, dev), None
 
 
 def test_library_loaded_is_in_tree():

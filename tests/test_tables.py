@@ -70,6 +70,17 @@ def test_file_and_dense_paths_agree(ct):
     assert ct.obs_slot == c2.obs_slot and ct.fips_weather == c2.fips_weather
 
 
+def test_compiled_fixture_is_current(ct, golden_dir):
+    import os
+
+    c2 = tables.CompiledTables.load_npz(os.path.join(golden_dir, "mini_compiled.npz"))
+    for k in tables.CompiledTables._ARRAYS:
+        np.testing.assert_array_equal(getattr(ct, k), getattr(c2, k))
+    for k in ("columns", "fips_weather", "years", "T", "fips_list", "n_samples", "obs_slot", "slot_of",
+              "baseline_keys", "effectiveness_keys", "sig_categories", "f32_exact"):
+        assert getattr(ct, k) == getattr(c2, k), k
+
+
 def test_schema_errors():
     sd = synth.make_synth("linear", n_fips=8, years=[2006], n_samples=2, seed=0)
     bad = dict(sd.weights)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 counter passes: N env steps of a bench workload plus calibration
+kernels of KNOWN HBM byte counts (a 1 GiB device copy and a 1 GiB fill), so FETCH_SIZE /
+WRITE_SIZE can be calibrated in this process (MI355X_MICROARCH.md §HBM: FETCH_SIZE reads 1/2
+on wide coalesced reads on gfx950; other shapes must be calibrated).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_probe.py
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from weather2alert_amd import HeatAlertVecEnv, synth, tables  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--workload", default="configs2")
+p.add_argument("--steps", type=int, default=24)
+p.add_argument("--num-envs", type=int, default=None)
+p.add_argument("--no-obs", action="store_true")
+a = p.parse_args()
+wname, n_default, augment, desc = bench.WORKLOADS[a.workload]
+n = a.num_envs or n_default
+dev = torch.device("cuda:0")
+sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
+ct = tables.compile_from_synth(sd)
+env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs)
+g = torch.Generator(device=dev).manual_seed(1234)
+pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
+env.reset(seed=0)
+# calibration: 1 GiB copy (reads 1 GiB, writes 1 GiB) and 1 GiB fill, float32
+src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+dst = torch.empty_like(src)
+torch.cuda.synchronize()
+for _ in range(3):
+    dst.copy_(src)
+    dst.fill_(1.0)
+torch.cuda.synchronize()
+for i in range(a.steps):
+    env.step(pool[i & 7])
+torch.cuda.synchronize()
+print("probe done", desc, "steps", a.steps)
+env.close()

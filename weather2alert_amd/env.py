@@ -204,8 +204,8 @@ class HeatAlertVecEnv:
         else:
             bud = np.broadcast_to(np.asarray(ep["budget"], dtype=np.int64), (n,))
         dev = self.device
-        t = {k: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=dev) for k, a in arrs.items()}
-        tb = torch.as_tensor(np.ascontiguousarray(bud), dtype=torch.int32, device=dev)
+        t = {k: torch.from_numpy(np.array(a, dtype=np.int32)).to(dev) for k, a in arrs.items()}
+        tb = torch.from_numpy(np.array(bud, dtype=np.int32)).to(dev)
         with torch.cuda.device(dev):
             _ffi.check(self._lib.w2a_reset(self._h, t["county_w"].data_ptr(), t["year_i"].data_ptr(),
                                            t["coef_col"].data_ptr(), t["sample"].data_ptr(), tb.data_ptr(),

@@ -105,6 +105,26 @@ class CompiledTables:
     def nbytes(self) -> int:
         return int(self.X.nbytes + self.W.nbytes + self.n_days.nbytes + self.B0.nbytes)
 
+    _ARRAYS = ("X", "n_days", "B0", "W", "fips_to_weather", "sim_cnt", "sim_ptr", "sim_idx")
+
+    def save_npz(self, path: str) -> None:
+        """Cache the compiled tables (skips pandas/pyarrow/safetensors at start-up)."""
+        import json
+
+        meta = {k: getattr(self, k) for k in ("columns", "fips_weather", "years", "T", "fips_list", "n_samples",
+                                              "obs_slot", "slot_of", "baseline_keys", "effectiveness_keys",
+                                              "sig_categories", "f32_exact")}
+        np.savez_compressed(path, meta_json=np.asarray(json.dumps(meta)),
+                            **{k: getattr(self, k) for k in self._ARRAYS})
+
+    @classmethod
+    def load_npz(cls, path: str) -> "CompiledTables":
+        import json
+
+        z = np.load(path)
+        meta = json.loads(str(z["meta_json"]))
+        return cls(**meta, **{k: z[k] for k in cls._ARRAYS})
+
 
 # ------------------------------------------------------------------------------------------
 def _assign_slots(columns: list[str], weight_names: set[str]) -> tuple[dict[str, int], list[int]]:
