@@ -68,7 +68,9 @@ enum { W2A_BUDGET_FIXED = 0, W2A_BUDGET_LESS_THAN = 1, W2A_BUDGET_CENTERED = 2 }
  *   slots 24..27  run-time fields: alert_lag1, alert_streak, remaining_budget, alert_2wks(agent)
  *   slot   28     25th table-sourced column if the schema has one (else 0)
  *   slot   29     bias input (the table stores 1.0)
- *   slots 30..31  zero
+ *   slot   30     copy of 'heat_qi' with a zero coefficient: the effectiveness gate
+ *                 heat_qi > 0.5 (env.py:218) is read here by lane 7
+ *   slot   31     zero
  * W rows use the same slots (zero where a slot has no coefficient), so a reward logit is a
  * plain 32-wide dot product. obs_slot[j] maps observation column j (reference order,
  * env.py:186-195: the 28 episode columns then 'alert_2wks') to its slot.
@@ -83,7 +85,7 @@ typedef struct w2a_tables {
   int32_t T, S_w, Y, S, n_samples;
   int32_t n_obs;                  /* observation width (29 with the reference schema)    */
   int32_t obs_slot[W2A_ROW_FLOATS]; /* obs column -> slot, first n_obs entries valid       */
-  int32_t slot_heat_qi;           /* slot of 'heat_qi' (effectiveness gate, env.py:218)  */
+  int32_t slot_heat_qi;           /* slot of the 'heat_qi' feature (informational; the gate reads slot 30) */
 } w2a_tables;
 
 typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */

@@ -1,0 +1,78 @@
+"""Multi-process path on CPU: world_size-2 gloo run of the sharding helpers and the episodic
+return all-gather that bench.py / users run over RCCL (one process per GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from weather2alert_amd import dist as wdist
+
+
+def test_shard_range_partitions_exactly():
+    for total in (1, 7, 8, 1000, 8388608):
+        for world in (1, 2, 3, 8):
+            spans = [wdist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_local, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = wdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    dev = torch.device("cpu")
+    start, stop = wdist.shard_range(n_local * world, rank, world)
+    assert (start, stop) == (rank * n_local, (rank + 1) * n_local)
+    # each rank's "finished episode returns": a function of the GLOBAL env id
+    gid = torch.arange(start, stop, dtype=torch.float32)
+    local = -100.0 - gid
+    g = wdist.ReturnGatherer(n_local, dev)
+    allr = g.gather(local)
+    expect = -100.0 - torch.arange(n_local * world, dtype=torch.float32)
+    ok = torch.equal(allr, expect)
+    m = float(g.mean(local))
+    mx = wdist.max_over_ranks(float(rank + 1), dev)
+    wdist.barrier()
+    q.put((rank, ok, m, mx))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_return_gather():
+    world, n_local = 2, 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    expect_mean = float((-100.0 - torch.arange(n_local * world, dtype=torch.float64)).mean())
+    for rank, ok, m, mx in res:
+        assert ok
+        assert abs(m - expect_mean) < 1e-9
+        assert mx == float(world)
+
+
+def test_single_process_gatherer_is_a_copy():
+    g = wdist.ReturnGatherer(5, torch.device("cpu"), world=1)
+    x = torch.arange(5, dtype=torch.float32)
+    assert torch.equal(g.gather(x), x)
+    assert float(g.mean(x)) == 2.0
