@@ -29,13 +29,19 @@ ALGO_BYTES_NO_OBS = 373
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 WORKLOADS = {
-    # name: (weights list, num_envs per GPU, similar_climate_counties, description)
-    "configs1": ("linear", 65536, False, "configs[1]: 65,536 envs, weights/linear (S=746), random county per env"),
-    "configs2": ("linear", 1048576, True,
+    # name: (weights list, num_envs per GPU, similar_climate_counties, reward_path, description)
+    "configs1": ("linear", 65536, False, "gather",
+                 "configs[1]: 65,536 envs, weights/linear (S=746), random county per env"),
+    "configs2": ("linear", 1048576, True, "gather",
                  "configs[2]: 1,048,576 envs, weights/linear (S=746), similar_climate_counties=True"),
-    "configs3": ("nn_full_medicare_all", 1048576, False,
-                 "configs[3]: 1,048,576 envs, nn_full_medicare_all shape (S=720), row-gather kernel"),
+    "configs3": ("nn_full_medicare_all", 1048576, False, "table",
+                 "configs[3]: 1,048,576 envs, nn_full_medicare_all shape (S=720), logit table from the grouped "
+                 "fp64-MFMA GEMM"),
+    "configs3_gather": ("nn_full_medicare_all", 1048576, False, "gather",
+                        "configs[3] shape on the row-gather kernel (A/B for the table path)"),
+    "configs1_table": ("linear", 65536, False, "table", "configs[1] shape on the logit-table path"),
 }
+ALGO_BYTES_TABLE = 305  # SURVEY §8d logit-table path
 
 
 def parse():
@@ -110,14 +116,17 @@ def main():
     torch.cuda.set_device(device)
     wdist.init_from_env("nccl", device)
 
-    wname, n_default, augment, desc = WORKLOADS[args.workload]
+    wname, n_default, augment, rpath, desc = WORKLOADS[args.workload]
     n = args.num_envs or n_default
     t_setup = time.perf_counter()
     sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
                           extra_confounder_fips=60)
     ct = tables.compile_from_synth(sd)
-    env = HeatAlertVecEnv(n, tables=ct, device=device, similar_climate_counties=augment, env_gid0=rank * n,
-                          write_obs=not args.no_obs)
+    dt = tables.DeviceTables(ct, device)
+    if rpath == "table":
+        dt.build_logit_table(timed=True)
+    env = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, env_gid0=rank * n,
+                          write_obs=not args.no_obs, reward_path=rpath)
     gather = wdist.ReturnGatherer(n, device)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
@@ -156,6 +165,8 @@ def main():
         total_env_steps = float(n) * world * args.steps
         per_launch_s = dev_ms * 1e-3 / args.steps
         bytes_per = ALGO_BYTES_NO_OBS if args.no_obs else ALGO_BYTES_PER_ENV_STEP
+        if rpath == "table":
+            bytes_per = ALGO_BYTES_TABLE - (116 if args.no_obs else 0)
         achieved = bytes_per * n / per_launch_s / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -172,11 +183,14 @@ def main():
             "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
                        "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
-                       "seed_mode": "device", "autoreset": "same_step",
+                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath,
+                       "logit_table_build_ms": dt.logit_build_ms,
+                       "logit_table_gb": None if dt.L is None else dt.L.numel() * 8 / 1e9,
                        "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step<autoreset,obs>", "avg_launch_us": per_launch_s * 1e6,
+                         "kernel": f"k_step<autoreset,obs={not args.no_obs},table={rpath == 'table'}>",
+                         "avg_launch_us": per_launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "timing": "HIP events on the launch stream around the timed steps / steps"},
             "kernel_env_steps_per_sec_per_gpu": n / per_launch_s,

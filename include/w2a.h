@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 1
+#define W2A_ABI_VERSION 2
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 #define W2A_LANES_PER_ENV 8
 
@@ -43,7 +43,9 @@ enum {
 enum {
   W2A_ST_BAD_EPISODE = 1, /* reset tuple out of range (reference: KeyError env.py:127 / ValueError :121) */
   W2A_ST_BAD_ACTION = 2,  /* action not in {0,1} (reference action_space = Discrete(2), env.py:95) */
-  W2A_ST_STEP_AFTER_DONE = 4 /* step() on a finished episode without autoreset */
+  W2A_ST_STEP_AFTER_DONE = 4, /* step() on a finished episode without autoreset */
+  W2A_ST_TABLE_MISMATCH = 8   /* an injected episode pairs a county's weather with another county's
+                                 coefficients: fine for the row-gather path, invalid for W2A_STEP_TABLE */
 };
 
 /* action buffer element types accepted by w2a_step */
@@ -52,7 +54,10 @@ enum { W2A_ACT_I32 = 0, W2A_ACT_I64 = 1, W2A_ACT_U8 = 2 };
 /* w2a_step flags */
 enum {
   W2A_STEP_AUTORESET = 1, /* same-step autoreset with the device RNG (needs w2a_set_autoreset) */
-  W2A_STEP_NO_OBS = 2     /* reward-only: skip the observation write */
+  W2A_STEP_NO_OBS = 2,    /* reward-only: skip the observation write */
+  W2A_STEP_TABLE = 4      /* logits from the precomputed table L (+ Wendo) instead of the coefficient-row gather;
+                             only for episodes whose coefficient column is the weather county's own (no
+                             similar_climate_counties augmentation) */
 };
 
 /* budget sampling of reset(sample_budget=..., sample_budget_type=...), env.py:172-177 */
@@ -86,6 +91,10 @@ typedef struct w2a_tables {
   int32_t n_obs;                  /* observation width (29 with the reference schema)    */
   int32_t obs_slot[W2A_ROW_FLOATS]; /* obs column -> slot, first n_obs entries valid       */
   int32_t slot_heat_qi;           /* slot of the 'heat_qi' feature (informational; the gate reads slot 30) */
+  /* optional logit-table path (all three or none): */
+  const int32_t *weather_to_fips; /* [S_w] county row of X -> its weight column, -1 = none                     */
+  const void *L;                  /* [T][S_w*Y][n_samples] double2 {baseline, gated effectiveness} exogenous logits */
+  const void *Wendo;              /* [S*n_samples][2][4] f32: coefficients of the 4 run-time slots per head    */
 } w2a_tables;
 
 typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */
@@ -141,6 +150,16 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
  * f32 [num_envs]) receives the finished episode's return. */
 int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, float *reward, uint8_t *done,
              float *last_return, int flags, void *stream);
+
+/* Dense reward precompute (BASELINE configs[3]/[4], "nn_full_medicare / MFMA path"; no counterpart in the
+ * reference, which re-evaluates the 2 x 28-term sums of env.py:207-217 every step): one grouped fp64-MFMA
+ * GEMM per county, L[t][county,year][sample] = {sum_k x_k*wb_k, sum_k x_k*we_k (or -inf when heat_qi <= 0.5)}
+ * over the table-sourced features + bias, and the compact run-time-slot coefficient rows Wendo. The caller
+ * owns both buffers (sizes from the two *_bytes functions) and passes them back in w2a_tables.L / .Wendo. */
+size_t w2a_logit_table_bytes(const w2a_tables *tables);
+size_t w2a_wendo_bytes(const w2a_tables *tables);
+int w2a_build_logit_table(const w2a_tables *tables, void *L, size_t L_bytes, void *Wendo, size_t Wendo_bytes,
+                          void *stream);
 
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);

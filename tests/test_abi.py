@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == 1
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 2
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
@@ -43,11 +43,16 @@ def test_host_only_entry_points(lib):
     assert b"NULL" in lib.w2a_last_error()
     assert lib.w2a_step(None, None, 0, None, None, None, None, 0, None) == -1
     assert lib.w2a_reset_device_rng(None, 0, -1, 0, -1, 0, 1, None, None, None) == -1
+    t = _ffi.Tables()
+    t.T, t.S_w, t.Y, t.S, t.n_samples = 153, 746, 11, 746, 100
+    assert lib.w2a_logit_table_bytes(C.byref(t)) == 153 * 746 * 11 * 100 * 16
+    assert lib.w2a_wendo_bytes(C.byref(t)) == 746 * 100 * 32
+    assert lib.w2a_build_logit_table(C.byref(t), None, 0, None, 0, None) == -1
 
 
 def test_ffi_struct_layout_matches_header():
-    # 6 pointers + 6 int32 + 32 int32 + 1 int32, naturally aligned
-    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4
+    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 3 pointers, naturally aligned
+    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 3 * 8
     assert C.sizeof(_ffi.StateView) == 15 * 8
 
 

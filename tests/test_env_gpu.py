@@ -119,8 +119,10 @@ def _random_tuples(ct, n, rng, augment):
                 sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 12, n))
 
 
-@pytest.mark.parametrize("n,augment,adversarial", [(4099, False, False), (65536, True, False), (8192, False, True)])
-def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial):
+@pytest.mark.parametrize("n,augment,adversarial,path", [
+    (4099, False, False, "gather"), (65536, True, False, "gather"), (8192, False, True, "gather"),
+    (4099, False, False, "table"), (8192, False, True, "table")])
+def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, path):
     """HIP path vs the float64 vector oracle over a full 153-step episode on a synthetic data set
     (64 counties x 4 years, 16 posterior draws). 'adversarial' uses unscaled N(0,1) coefficients
     (logit terms up to ~150 with cancellation) to show the fp64 accumulation holds the 1e-5 bar."""
@@ -133,8 +135,9 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial):
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
     rng = np.random.default_rng(n)
     ep = _random_tuples(ct, n, rng, augment)
-    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_path=path)
     obs, _ = env.reset(options={"episodes": ep})
+    assert env.check_status() == 0
     obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
     np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
     worst = 0.0
@@ -153,7 +156,57 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial):
     np.testing.assert_array_equal(st["t"], V.t)
     np.testing.assert_array_equal(st["hist14"], (V.hist * (1 << np.arange(13, -1, -1))).sum(axis=1))
     np.testing.assert_array_equal(st["budget"] - st["used"], V.budget - V.used)
-    print(f"n={n} adversarial={adversarial}: max |reward - oracle| = {worst:.3e}")
+    print(f"n={n} adversarial={adversarial} path={path}: max |reward - oracle| = {worst:.3e}")
+    env.close()
+
+
+def test_logit_table_matches_float64_contraction(dev):
+    """The grouped fp64-MFMA precompute (k_logit_table) against a NumPy float64 einsum: every
+    (day, county, year, posterior draw, head), gate folded in as -inf; and the packed run-time-slot rows."""
+    from weather2alert_amd.tables import DeviceTables
+
+    sd = synth.make_synth("linear", n_fips=20, n_counties_weather=13, years=[2006, 2007, 2008], n_samples=11, seed=21,
+                          weight_scale=None, weight_sigma=1.0)
+    ct = tables.compile_from_synth(sd)
+    dt = DeviceTables(ct, dev).build_logit_table(timed=True)
+    L = dt.L.cpu().numpy()  # [T, S_w*Y, n_samples, 2]
+    X = ct.X.astype(np.float64)  # [T, R, 32]
+    W = ct.W.reshape(ct.S, ct.n_samples, 2, 32).astype(np.float64)
+    w2f = dt.weather_to_fips.cpu().numpy()
+    tab = [k for k in range(32) if k not in (24, 25, 26, 27)]
+    assert (w2f >= 0).all() and len(set(w2f.tolist())) == ct.S_w
+    for c in range(ct.S_w):
+        rows = slice(c * ct.Y, (c + 1) * ct.Y)
+        ref = np.einsum("trk,shk->trsh", X[:, rows][:, :, tab], W[w2f[c]][:, :, tab])
+        closed = ~(ct.X[:, rows, 30] > 0.5)
+        ref[..., 1][closed] = -np.inf
+        got = L[:, rows]
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), fin)
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-13, atol=1e-13)
+    Wendo = dt.Wendo.cpu().numpy()
+    np.testing.assert_array_equal(Wendo, ct.W[:, :, 24:28])
+    assert (~np.isfinite(L[..., 1])).mean() > 0.2  # roughly half the gates are closed
+    print("logit-table build ms:", dt.logit_build_ms)
+
+
+def test_table_path_rejects_augmentation(dev, mini):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    d, meta, ct, dt, _ = mini
+    with pytest.raises(ValueError):
+        HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", similar_climate_counties=True)
+    env = HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", autoreset="disabled")
+    with pytest.raises(ValueError):
+        env.reset(seed=0, options={"similar_climate_counties": True})
+    # an injected tuple that pairs county 0's weather with county 1's coefficients is flagged
+    env.reset(options={"episodes": dict(county_w=0, year_i=0, coef_col=(int(dt.weather_to_fips[0]) + 1) % ct.S,
+                                        sample=0)})
+    with pytest.raises(ValueError):
+        env.check_status()
+    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto").reward_path == "table"
+    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto",
+                           similar_climate_counties=True).reward_path == "gather"
     env.close()
 
 
@@ -198,7 +251,8 @@ def test_device_rng_reset_matches_restatement(dev):
     env.close()
 
 
-def test_same_step_autoreset_and_shard_invariance(dev):
+@pytest.mark.parametrize("path", ["gather", "table"])
+def test_same_step_autoreset_and_shard_invariance(dev, path):
     """Lock-step autoreset on the device: after 153 steps every env restarts inside the same
     call; final returns are reported; and two half-size shards keyed by global env id give the
     same trajectories as one full-size env (multi-GPU correctness by construction)."""
@@ -207,10 +261,10 @@ def test_same_step_autoreset_and_shard_invariance(dev):
     sd = synth.make_synth("linear", n_fips=32, years=[2006, 2007], n_samples=6, seed=5)
     ct = tables.compile_from_synth(sd)
     n = 2048 + 40
-    full = HeatAlertVecEnv(n, tables=ct, device=dev)
+    full = HeatAlertVecEnv(n, tables=ct, device=dev, reward_path=path)
     h = n // 2
-    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0), HeatAlertVecEnv(n - h, tables=ct, device=dev,
-                                                                                   env_gid0=h)]
+    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0, reward_path=path),
+             HeatAlertVecEnv(n - h, tables=ct, device=dev, env_gid0=h, reward_path="gather")]
     o_full, _ = full.reset(seed=77)
     o_parts = [p.reset(seed=77)[0] for p in parts]
     assert torch.equal(o_full, torch.cat(o_parts))
@@ -221,7 +275,11 @@ def test_same_step_autoreset_and_shard_invariance(dev):
         o, r, d, _, info = full.step(a.to(dev))
         outs = [p.step(a[s].to(dev)) for p, s in zip(parts, (slice(0, h), slice(h, n)))]
         assert torch.equal(o, torch.cat([x[0] for x in outs]))
-        assert torch.equal(r, torch.cat([x[1] for x in outs]))
+        r_parts = torch.cat([x[1] for x in outs])
+        if path == "gather":
+            assert torch.equal(r, r_parts)
+        else:  # second shard runs the row-gather kernel: table vs gather agree to f32 rounding of the sigmoid input
+            assert torch.allclose(r, r_parts, rtol=0, atol=2e-6)
         assert torch.equal(d, torch.cat([x[2] for x in outs]))
         if t < 153:
             ret += r.cpu().double()

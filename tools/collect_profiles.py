@@ -27,7 +27,7 @@ def main():
     out = os.path.join(ROOT, "profiles", a.tag)
     os.makedirs(out, exist_ok=True)
     # 1. rocprofv3 --kernel-trace --stats summary of `python3 bench.py` (names trimmed)
-    ks = glob.glob(os.path.join(GO, "prof_kt", "**", "*kernel_stats.csv"), recursive=True)
+    ks = glob.glob(os.path.join(GO, f"prof_kt_{a.workload}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
         rows = list(csv.reader(open(ks[0])))
         with open(os.path.join(out, f"kernel_stats_{a.workload}.csv"), "w", newline="") as f:
@@ -37,8 +37,8 @@ def main():
                 w.writerow(r)
     # 2. PMC passes (tools/pmc_probe.py): per-kernel means
     pmc = {}
-    for name in ("prof_fetch", "prof_write", "prof_tcc", "prof_sq"):
-        fp = os.path.join(GO, name + ".summary.json")
+    for name in ("prof_fetch", "prof_write", "prof_tcc", "prof_sq", "prof_mfma"):
+        fp = os.path.join(GO, f"{name}_{a.workload}.summary.json")
         if os.path.exists(fp):
             for k, v in json.load(open(fp)).items():
                 if "k_step" in k or "k_reset" in k or "k_logit" in k or "copyBuffer" in k or "FillFunctor" in k:
@@ -46,7 +46,7 @@ def main():
     # calibration from the raw CSVs: the 1 GiB copy / fill launches are the big ones
     calib = {}
     for name, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
-        for f in glob.glob(os.path.join(GO, name, "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(GO, f"{name}_{a.workload}", "**", "*counter_collection.csv"), recursive=True):
             per = {}
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == ctr:
@@ -76,7 +76,9 @@ def main():
         cur[a.workload] = rd + wr
         json.dump(cur, open(tl, "w"), indent=1)
     json.dump(res, open(os.path.join(out, f"pmc_{a.workload}.json"), "w"), indent=1)
-    for f in ("bench.log", "bench_c1.log", "bench_c3.log", "pytest_gpu.log", "smoke.log"):
+    logs = ["bench.log", "pytest_gpu.log", "smoke.log"] + [os.path.basename(x) for x in
+                                                           glob.glob(os.path.join(GO, "bench_*.log"))]
+    for f in logs:
         src = os.path.join(GO, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(out, f))

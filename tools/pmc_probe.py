@@ -23,12 +23,13 @@ p.add_argument("--steps", type=int, default=24)
 p.add_argument("--num-envs", type=int, default=None)
 p.add_argument("--no-obs", action="store_true")
 a = p.parse_args()
-wname, n_default, augment, desc = bench.WORKLOADS[a.workload]
+wname, n_default, augment, rpath, desc = bench.WORKLOADS[a.workload]
 n = a.num_envs or n_default
 dev = torch.device("cuda:0")
 sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
-env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs)
+env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs,
+                      reward_path=rpath)
 g = torch.Generator(device=dev).manual_seed(1234)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
 env.reset(seed=0)

@@ -10,15 +10,17 @@ ROW_FLOATS = 32
 LANES_PER_ENV = 8
 
 OK = 0
-ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
+ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS = 1, 2
+STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE = 1, 2, 4
+ABI_VERSION = 2
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
 # every symbol include/w2a.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
+    "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
 ]
 
 
@@ -28,6 +30,7 @@ class Tables(C.Structure):
         ("fips_to_weather", C.c_void_p), ("sim_cnt", C.c_void_p),
         ("T", C.c_int32), ("S_w", C.c_int32), ("Y", C.c_int32), ("S", C.c_int32), ("n_samples", C.c_int32),
         ("n_obs", C.c_int32), ("obs_slot", C.c_int32 * ROW_FLOATS), ("slot_heat_qi", C.c_int32),
+        ("weather_to_fips", C.c_void_p), ("L", C.c_void_p), ("Wendo", C.c_void_p),
     ]
 
 
@@ -88,8 +91,14 @@ def load(build_if_missing: bool = True):
     lib.w2a_get_state.argtypes = [vp, C.POINTER(StateView), vp]
     lib.w2a_read_status.restype = C.c_int
     lib.w2a_read_status.argtypes = [vp, C.POINTER(i32), vp]
-    if lib.w2a_abi_version() != 1:
-        raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != 1; rebuild")
+    lib.w2a_logit_table_bytes.restype = C.c_size_t
+    lib.w2a_logit_table_bytes.argtypes = [C.POINTER(Tables)]
+    lib.w2a_wendo_bytes.restype = C.c_size_t
+    lib.w2a_wendo_bytes.argtypes = [C.POINTER(Tables)]
+    lib.w2a_build_logit_table.restype = C.c_int
+    lib.w2a_build_logit_table.argtypes = [C.POINTER(Tables), vp, C.c_size_t, vp, C.c_size_t, vp]
+    if lib.w2a_abi_version() != ABI_VERSION:
+        raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

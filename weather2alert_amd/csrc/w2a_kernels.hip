@@ -38,7 +38,7 @@
 // ----------------------------------------------------------------------------------------
 // packed state
 // ----------------------------------------------------------------------------------------
-// cold (uint4): x = ep_row (county_w*Y + year_i), y = ep_w (coef_col*n_samples + sample),
+// cold (uint4): x = ep_row (county_w*Y + year_i), y = coef_col << 12 | sample (n_samples <= 4096),
 //               z = sticky budget (int, -1 unset), w = episode number
 // hot  (uint4): x = dyn0: t[0:10) used[10:20) streak[20:30) last_actual[30] at_budget[31]
 //               y = dyn1: hist14[0:14) n_days[16:26) finished[31]
@@ -67,8 +67,15 @@ struct DevTables {
   const float4 *W;
   const int32_t *fips_to_weather;
   const int32_t *sim_cnt;
+  const int32_t *weather_to_fips;  // [S_w] inverse of fips_to_weather (-1: county has no coefficients); nullable
+  const double2 *L;                // [T][S_w*Y][n_samples] {baseline, gated effectiveness} exogenous logits; nullable
+  const float4 *Wendo;             // [S*n_samples][2] run-time-slot coefficients (slots 24..27) per head; nullable
   int32_t T, S_w, Y, S, n_samples, n_obs;
 };
+#define SAMPLE_BITS 12
+#define PACK_W(coef_col, sample) (((uint32_t)(coef_col) << SAMPLE_BITS) | (uint32_t)(sample))
+#define W_COL(y) ((y) >> SAMPLE_BITS)
+#define W_SAMPLE(y) ((y) & ((1u << SAMPLE_BITS) - 1u))
 
 struct ResetCfg {
   uint64_t seed;
@@ -170,7 +177,7 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
   int32_t cw = tb.fips_to_weather[county];
   if (cw < 0) { cw = 0; bad = 1; }
   e.ep_row = (uint32_t)cw * (uint32_t)tb.Y + year_i;
-  e.ep_w = coef_col * (uint32_t)tb.n_samples + sample;
+  e.ep_w = PACK_W(coef_col, sample);
   int32_t nd = tb.n_days[e.ep_row];
   if (nd <= 0) { bad = 1; nd = 1; }
   e.ndays = (uint32_t)nd;
@@ -248,7 +255,7 @@ struct StepArgs {
   int32_t act_dtype;
 };
 
-template <bool AUTORESET, bool WRITE_OBS>
+template <bool AUTORESET, bool WRITE_OBS, bool TABLE>
 __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
@@ -281,36 +288,53 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
   const uint32_t used2 = used + actual;
   const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
 
-  // gathers: feature row of day t (pre-increment, Q6) and the env's two coefficient rows
+  // gathers: feature row of day t (pre-increment, Q6) and the env's coefficients
   const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
-  const float4 *xp = a.tb.X + ((size_t)t * rows_per_day + cold.x) * (ROWF / 4) + l;
-  const float4 *wp = a.tb.W + (size_t)cold.y * (2 * ROWF / 4) + l;
-  float4 x = *xp;
-  const float4 wb = wp[0];
-  const float4 we = wp[ROWF / 4];
+  const size_t day_row = (size_t)t * rows_per_day + cold.x;
+  const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WRITE_OBS || !TABLE) x = a.tb.X[day_row * (ROWF / 4) + l];
   const int4 so = reinterpret_cast<const int4 *>(a.slot_obs)[l];
-
-  // env.py:190-193 run-time fields live in slots 24..27 = lane 6
-  if (l == 6) {
-    x.x = (t > 0) ? (float)actual : 0.0f;          // alert_lag1: today's action for t>0 (Q3)
-    x.y = (float)streak;                           // streak before today's action (Q4)
-    x.z = (float)(budget - (int32_t)used2);        // remaining_budget
-    x.w = (float)__popc(hist2);                    // agent's 14-day count ('alert_2wks', Q1)
+  // env.py:190-193 run-time fields (slots 24..27 = lane 6)
+  const float f_lag1 = (t > 0) ? (float)actual : 0.0f;   // alert_lag1: today's action for t>0 (Q3)
+  const float f_streak = (float)streak;                  // streak before today's action (Q4)
+  const float f_rem = (float)(budget - (int32_t)used2);  // remaining_budget
+  const float f_a2w = (float)__popc(hist2);              // agent's 14-day count ('alert_2wks', Q1)
+  if (l == 6) x = make_float4(f_lag1, f_streak, f_rem, f_a2w);
+  double zb, ze;
+  if (TABLE) {
+    // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
+    // add the four run-time terms. Every lane of the group computes the same value (broadcast loads).
+    const double2 lv = a.tb.L[day_row * (size_t)a.tb.n_samples + W_SAMPLE(cold.y)];
+    const float4 qb = a.tb.Wendo[(size_t)wrow * 2];
+    const float4 qe = a.tb.Wendo[(size_t)wrow * 2 + 1];
+    zb = fma((double)f_lag1, (double)qb.x, lv.x);
+    zb = fma((double)f_streak, (double)qb.y, zb);
+    zb = fma((double)f_rem, (double)qb.z, zb);
+    zb = fma((double)f_a2w, (double)qb.w, zb);
+    ze = fma((double)f_lag1, (double)qe.x, lv.y);
+    ze = fma((double)f_streak, (double)qe.y, ze);
+    ze = fma((double)f_rem, (double)qe.z, ze);
+    ze = fma((double)f_a2w, (double)qe.w, ze);
+  } else {
+    const float4 *wp = a.tb.W + (size_t)wrow * (2 * ROWF / 4) + l;
+    const float4 wb = wp[0];
+    const float4 we = wp[ROWF / 4];
+    // env.py:207-217: two 28-term dot products, fp64 accumulation
+    zb = (double)x.x * (double)wb.x;
+    zb = fma((double)x.y, (double)wb.y, zb);
+    zb = fma((double)x.z, (double)wb.z, zb);
+    zb = fma((double)x.w, (double)wb.w, zb);
+    ze = (double)x.x * (double)we.x;
+    ze = fma((double)x.y, (double)we.y, ze);
+    ze = fma((double)x.z, (double)we.z, ze);
+    ze = fma((double)x.w, (double)we.w, ze);
+    // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 (lane 7, .z) holds a copy of heat_qi with a
+    // zero coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
+    if (l == 7 && !(x.z > 0.5f)) ze = -__builtin_inf();
+    zb = group_sum(zb);
+    ze = group_sum(ze);
   }
-  // env.py:207-217: two 28-term dot products, fp64 accumulation
-  double zb = (double)x.x * (double)wb.x;
-  zb = fma((double)x.y, (double)wb.y, zb);
-  zb = fma((double)x.z, (double)wb.z, zb);
-  zb = fma((double)x.w, (double)wb.w, zb);
-  double ze = (double)x.x * (double)we.x;
-  ze = fma((double)x.y, (double)we.y, ze);
-  ze = fma((double)x.z, (double)we.z, ze);
-  ze = fma((double)x.w, (double)we.w, ze);
-  // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 (lane 7, .z) holds a copy of heat_qi with a
-  // zero coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
-  if (l == 7 && !(x.z > 0.5f)) ze = -__builtin_inf();
-  zb = group_sum(zb);
-  ze = group_sum(ze);
   const float base = sigmoid_f32((float)zb);
   const float eff = sigmoid_f32((float)ze);
   // env.py:221
@@ -398,7 +422,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     if (cc < 0 || cc >= a.tb.S) { cc = 0; bad = 1; }
     if (sm < 0 || sm >= a.tb.n_samples) { sm = 0; bad = 1; }
     ep.ep_row = (uint32_t)cw * (uint32_t)a.tb.Y + (uint32_t)yi;
-    ep.ep_w = (uint32_t)cc * (uint32_t)a.tb.n_samples + (uint32_t)sm;
+    ep.ep_w = PACK_W(cc, sm);
+    // the logit-table path needs coefficient column == the weather county's own column
+    if (a.tb.weather_to_fips && a.tb.weather_to_fips[cw] != cc) bad |= 2;
     int32_t nd = a.tb.n_days[ep.ep_row];
     if (nd <= 0) { nd = 1; bad = 1; }
     ep.ndays = (uint32_t)nd;
@@ -414,7 +440,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   if (valid && sel && l == 0) {
     a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
     a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
-    if (bad) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
+    if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
+    if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
   }
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, l, x, so, sel);
 }
@@ -443,10 +470,109 @@ __global__ void k_get_state(const uint4 *cold, const uint4 *hot, int64_t n, int3
   if (v.episode_return) v.episode_return[i] = __uint_as_float(h.z);
   if (v.county_w) v.county_w[i] = (int32_t)(c.x / (uint32_t)Y);
   if (v.year_i) v.year_i[i] = (int32_t)(c.x % (uint32_t)Y);
-  if (v.coef_col) v.coef_col[i] = (int32_t)(c.y / (uint32_t)n_samples);
-  if (v.sample) v.sample[i] = (int32_t)(c.y % (uint32_t)n_samples);
+  if (v.coef_col) v.coef_col[i] = (int32_t)W_COL(c.y);
+  if (v.sample) v.sample[i] = (int32_t)W_SAMPLE(c.y);
   if (v.sticky_budget) v.sticky_budget[i] = (int32_t)c.z;
   if (v.episode_no) v.episode_no[i] = (int32_t)c.w;
+}
+
+
+// ----------------------------------------------------------------------------------------
+// logit-table precompute ("dense reward GEMM", BASELINE configs[3]/[4])
+// ----------------------------------------------------------------------------------------
+// For every weather county c with coefficient column cc = weather_to_fips[c]:
+//     D_c [M = Y*T rows (t-major)] [N = 2*n_samples cols (2*s + head)]  =  A_c [M][K=28] * B_c [K][N]
+// A_c = the county's feature rows (table slots 0..23 and 28..31: exogenous features, bias input,
+// gate copy and pad, the last two with zero coefficients), B_c = its posterior coefficient rows.
+// fp64 MFMA (v_mfma_f64_16x16x4_f64: A one f64 per lane A[l&15][l>>4], B[l>>4][l&15], D col = l&15,
+// row = (l>>4) + 4*reg) keeps the 1e-5 reward bar: products of f32 inputs are exact in fp64.
+// The heat_qi gate (env.py:218) is folded in: effectiveness logits of closed-gate rows are -inf.
+// Output L[(t*R + c*Y + y)][s] = {baseline, effectiveness} (double2), the layout k_step<TABLE> gathers.
+#define LT_K 28
+#define LT_NT 13  // n-tiles (16 cols) staged per pass: 208 columns = 2*100 samples padded
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lt_slot(int k) { return k < 24 ? k : k + 4; }
+
+struct LogitArgs {
+  DevTables tb;
+  double *L;
+  int32_t msplit;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_logit_table(const LogitArgs a) {
+  __shared__ float sB[LT_K][LT_NT * 16];
+  const int c = blockIdx.x;
+  const int cc = a.tb.weather_to_fips[c];
+  if (cc < 0) return;  // uniform per workgroup: county without coefficients
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Y = a.tb.Y, M = a.tb.Y * a.tb.T, N2 = 2 * a.tb.n_samples;
+  const int R = a.tb.S_w * a.tb.Y;
+  const int mtiles = (M + 15) >> 4;
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const float *Wf = reinterpret_cast<const float *>(a.tb.W);
+  const int q = lane >> 4, col = lane & 15;
+  for (int n0 = 0; n0 < N2; n0 += LT_NT * 16) {
+    __syncthreads();
+    for (int idx = tid; idx < LT_K * LT_NT * 16; idx += BLOCK) {
+      const int nn = idx / LT_K, k = idx - nn * LT_K;
+      const int n = n0 + nn;
+      float v = 0.0f;
+      if (n < N2) v = Wf[((size_t)(cc * a.tb.n_samples + (n >> 1)) * 2 + (n & 1)) * ROWF + lt_slot(k)];
+      sB[k][nn] = v;
+    }
+    __syncthreads();
+    const int ntiles = min(LT_NT, (N2 - n0 + 15) >> 4);
+    for (int mt = blockIdx.y * (BLOCK / 64) + wave; mt < mtiles; mt += (BLOCK / 64) * a.msplit) {
+      // A fragments: row m = mt*16 + col (clamped), k = 4*ks + q
+      const int m = min(mt * 16 + col, M - 1);
+      const int tA = m / Y, yA = m - tA * Y;
+      const float *xr = Xf + ((size_t)tA * R + (size_t)c * Y + yA) * ROWF;
+      double af[LT_K / 4];
+#pragma unroll
+      for (int ks = 0; ks < LT_K / 4; ++ks) af[ks] = (double)xr[lt_slot(4 * ks + q)];
+      // this lane's 4 output rows: q + 4j
+      size_t orow[4];
+      bool ok[4], gate[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mj = mt * 16 + q + 4 * j;
+        ok[j] = mj < M;
+        const int mm = min(mj, M - 1);
+        const int tj = mm / Y, yj = mm - tj * Y;
+        orow[j] = (size_t)tj * R + (size_t)c * Y + yj;
+        gate[j] = Xf[orow[j] * ROWF + 30] > 0.5f;
+      }
+      for (int nt = 0; nt < ntiles; ++nt) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < LT_K / 4; ++ks) {
+          const double b = (double)sB[4 * ks + q][nt * 16 + col];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b, acc, 0, 0, 0);
+        }
+        const int n = n0 + nt * 16 + col;
+        if (n < N2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (ok[j]) {
+              double v = acc[j];
+              if ((n & 1) && !gate[j]) v = -__builtin_inf();
+              a.L[orow[j] * (size_t)N2 + n] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Wendo[i] = {W[i][0][24..27], W[i][1][24..27]}: the run-time-slot coefficients, 32 B per (column, draw)
+__global__ void k_pack_wendo(const float4 *W, float4 *Wendo, int64_t rows) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) {
+    Wendo[2 * i] = W[i * (2 * ROWF / 4) + 6];
+    Wendo[2 * i + 1] = W[i * (2 * ROWF / 4) + ROWF / 4 + 6];
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -477,8 +603,15 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
     return fail(W2A_ERR_ARG, "w2a_create: NULL table pointer");
   if (t->T <= 0 || t->T > 1023 || t->S_w <= 0 || t->Y <= 0 || t->S <= 0 || t->n_samples <= 0)
     return fail(W2A_ERR_SCHEMA, "w2a_create: table dims out of range (need 0 < T <= 1023, positive S_w, Y, S, n_samples)");
-  if ((int64_t)t->S_w * t->Y > 0x7FFFFFFFll / 2 || (int64_t)t->S * t->n_samples > 0x7FFFFFFFll / 2)
+  if ((int64_t)t->S_w * t->Y > 0x7FFFFFFFll / 2 || (int64_t)t->S * t->n_samples > 0x7FFFFFFFll / 2 ||
+      (int64_t)t->T * t->S_w * t->Y > 0x7FFFFFFFll)
     return fail(W2A_ERR_SCHEMA, "w2a_create: table too large for 32-bit row indices");
+  if (t->n_samples > (1 << SAMPLE_BITS) || t->S >= (1 << (32 - SAMPLE_BITS)))
+    return fail(W2A_ERR_SCHEMA, "w2a_create: need n_samples <= 4096 and S < 2^20");
+  if ((t->L != nullptr) != (t->Wendo != nullptr) || (t->L && !t->weather_to_fips))
+    return fail(W2A_ERR_ARG, "w2a_create: L, Wendo and weather_to_fips must be given together");
+  if (((uintptr_t)t->L & 15) || ((uintptr_t)t->Wendo & 15))
+    return fail(W2A_ERR_STATE, "w2a_create: L and Wendo must be 16-B aligned");
   if (t->n_obs <= 0 || t->n_obs > W2A_ROW_FLOATS) return fail(W2A_ERR_SCHEMA, "w2a_create: n_obs must be in 1..32");
   if (state_bytes < w2a_state_bytes(num_envs)) return fail(W2A_ERR_STATE, "w2a_create: state buffer too small");
   if (((uintptr_t)state & 255) || ((uintptr_t)t->X & 15) || ((uintptr_t)t->W & 15))
@@ -497,6 +630,9 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->tb.W = reinterpret_cast<const float4 *>(t->W);
   h->tb.fips_to_weather = t->fips_to_weather;
   h->tb.sim_cnt = t->sim_cnt;
+  h->tb.weather_to_fips = t->weather_to_fips;
+  h->tb.L = reinterpret_cast<const double2 *>(t->L);
+  h->tb.Wendo = reinterpret_cast<const float4 *>(t->Wendo);
   h->tb.T = t->T; h->tb.S_w = t->S_w; h->tb.Y = t->Y; h->tb.S = t->S; h->tb.n_samples = t->n_samples;
   h->tb.n_obs = t->n_obs;
   h->n = num_envs;
@@ -575,6 +711,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_step: bad action_dtype");
   const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
   const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
+  const bool table = (flags & W2A_STEP_TABLE) != 0;
+  if (table && !env->tb.L) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_TABLE needs tables with L/Wendo (w2a_build_logit_table)");
+  if (table && autoreset && env->autoreset.augment)
+    return fail(W2A_ERR_ARG, "w2a_step: the logit-table path cannot serve similar_climate_counties episodes");
   if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
   if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
@@ -585,13 +725,57 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
-  if (autoreset) {
-    if (no_obs) hipLaunchKernelGGL((k_step<true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_step<true, true>), grid, block, 0, s, a);
-  } else {
-    if (no_obs) hipLaunchKernelGGL((k_step<false, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_step<false, true>), grid, block, 0, s, a);
+#define W2A_LAUNCH(AR, OB, TB) hipLaunchKernelGGL((k_step<AR, OB, TB>), grid, block, 0, s, a)
+  const int variant = (autoreset ? 4 : 0) | (no_obs ? 0 : 2) | (table ? 1 : 0);
+  switch (variant) {
+    case 0: W2A_LAUNCH(false, false, false); break;
+    case 1: W2A_LAUNCH(false, false, true); break;
+    case 2: W2A_LAUNCH(false, true, false); break;
+    case 3: W2A_LAUNCH(false, true, true); break;
+    case 4: W2A_LAUNCH(true, false, false); break;
+    case 5: W2A_LAUNCH(true, false, true); break;
+    case 6: W2A_LAUNCH(true, true, false); break;
+    default: W2A_LAUNCH(true, true, true); break;
   }
+#undef W2A_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+
+size_t w2a_logit_table_bytes(const w2a_tables *t) {
+  if (!t || t->T <= 0 || t->S_w <= 0 || t->Y <= 0 || t->n_samples <= 0) return 0;
+  return (size_t)t->T * t->S_w * t->Y * t->n_samples * sizeof(double2);
+}
+
+size_t w2a_wendo_bytes(const w2a_tables *t) {
+  if (!t || t->S <= 0 || t->n_samples <= 0) return 0;
+  return (size_t)t->S * t->n_samples * 2 * sizeof(float4);
+}
+
+int w2a_build_logit_table(const w2a_tables *t, void *L, size_t L_bytes, void *Wendo, size_t Wendo_bytes, void *stream) {
+  if (!t || !L || !Wendo) return fail(W2A_ERR_ARG, "w2a_build_logit_table: NULL argument");
+  if (!t->X || !t->W || !t->weather_to_fips) return fail(W2A_ERR_ARG, "w2a_build_logit_table: X, W and weather_to_fips are required");
+  if (L_bytes < w2a_logit_table_bytes(t) || Wendo_bytes < w2a_wendo_bytes(t))
+    return fail(W2A_ERR_STATE, "w2a_build_logit_table: output buffer too small");
+  if (((uintptr_t)L & 15) || ((uintptr_t)Wendo & 15)) return fail(W2A_ERR_STATE, "w2a_build_logit_table: buffers must be 16-B aligned");
+  if ((int64_t)t->T * t->S_w * t->Y > 0x7FFFFFFFll) return fail(W2A_ERR_SCHEMA, "w2a_build_logit_table: table too large");
+  LogitArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tb.X = reinterpret_cast<const float4 *>(t->X);
+  a.tb.W = reinterpret_cast<const float4 *>(t->W);
+  a.tb.weather_to_fips = t->weather_to_fips;
+  a.tb.T = t->T; a.tb.S_w = t->S_w; a.tb.Y = t->Y; a.tb.S = t->S; a.tb.n_samples = t->n_samples;
+  a.L = reinterpret_cast<double *>(L);
+  a.msplit = 4;
+  hipStream_t s = (hipStream_t)stream;
+  // rows of absent (county, year) pairs and of counties without coefficients are never gathered; zero them anyway
+  HIP_TRY(hipMemsetAsync(L, 0, w2a_logit_table_bytes(t), s));
+  hipLaunchKernelGGL(k_logit_table, dim3((unsigned)t->S_w, (unsigned)a.msplit), dim3(BLOCK), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  const int64_t rows = (int64_t)t->S * t->n_samples;
+  hipLaunchKernelGGL(k_pack_wendo, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float4 *>(t->W), reinterpret_cast<float4 *>(Wendo), rows);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }

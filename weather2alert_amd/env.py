@@ -40,6 +40,11 @@ class HeatAlertVecEnv:
     autoreset            "same_step" (finished envs restart inside the same step() call and the
                          returned observation is the new episode's first one; the finished
                          episode's return is in info["final_return"]) or "disabled".
+    reward_path          "gather": each step gathers the env's two 128-B coefficient rows and sums the 28
+                         terms (works for every episode); "table": logits come from a table precomputed once
+                         by a grouped fp64-MFMA GEMM (DeviceTables.build_logit_table) -- less memory traffic
+                         per step, but only for episodes whose coefficients are the weather county's own,
+                         i.e. without similar_climate_counties; "auto": table unless augmentation is on.
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -62,6 +67,7 @@ class HeatAlertVecEnv:
         tables: CompiledTables | DeviceTables | None = None,
         env_gid0: int = 0,
         write_obs: bool = True,
+        reward_path: Literal["gather", "table", "auto"] = "gather",
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -85,6 +91,16 @@ class HeatAlertVecEnv:
         else:
             ct = tables if tables is not None else compile_from_files(data_dir, weights, split, years)
             self.dtables = DeviceTables(ct, self.device)
+        if reward_path not in ("gather", "table", "auto"):
+            raise ValueError(f"reward_path {reward_path!r}")
+        if reward_path == "auto":
+            reward_path = "gather" if self.similar_climate_counties else "table"
+        if reward_path == "table" and self.similar_climate_counties:
+            raise ValueError("reward_path='table' cannot serve similar_climate_counties=True (Q8 pairs a county's "
+                             "weather with another county's coefficients); use 'gather'")
+        self.reward_path = reward_path
+        if reward_path == "table":
+            self.dtables.build_logit_table()
         ct = self.ct = self.dtables.ct
         self.fips_list = ct.fips_list
         self.valid_years = ct.years
@@ -144,7 +160,10 @@ class HeatAlertVecEnv:
                            "(reference: KeyError at env.py:127 / ValueError at env.py:121)")
         if bits & _ffi.ST_BAD_ACTION:
             raise ValueError("step: actions must be 0 or 1 (action_space = Discrete(2))")
-        return bits
+        if (bits & _ffi.ST_TABLE_MISMATCH) and self.reward_path == "table":
+            raise ValueError("reset: an injected episode uses another county's coefficients; "
+                             "reward_path='table' cannot serve it (use 'gather')")
+        return bits & ~_ffi.ST_TABLE_MISMATCH
 
     def state(self) -> dict[str, torch.Tensor]:
         """Decoded per-env integer state (device tensors)."""
@@ -246,6 +265,8 @@ class HeatAlertVecEnv:
                 raise ValueError(f"{location!r} is not in list")  # env.py:121 list.index
             county = self._fips_pos[location]
             if bool(self._per_env(aug_o, i)):
+                if self.reward_path == "table":
+                    raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
                 ns = int(ct.sim_cnt[county])
                 if ns == 0:
                     raise KeyError(location)  # confounders.loc[fips] (datautils.py:123)
@@ -285,6 +306,8 @@ class HeatAlertVecEnv:
             if self.ct.fips_to_weather[loc_i] < 0:
                 raise KeyError(loc)
         aug = bool(self._opt(options, "similar_climate_counties", self.similar_climate_counties))
+        if aug and self.reward_path == "table":
+            raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
         bk = self._ctor_budget if self._ctor_budget is not None else options.get("budget")
         mode = _ffi.BUDGET_FIXED
         if self._opt(options, "sample_budget", False):
@@ -327,6 +350,8 @@ class HeatAlertVecEnv:
         if not actions.is_contiguous():
             actions = actions.contiguous()
         flags = 0 if self.write_obs else _ffi.STEP_NO_OBS
+        if self.reward_path == "table":
+            flags |= _ffi.STEP_TABLE
         dev_auto = self.autoreset == "same_step" and self.seed_mode == "device"
         if dev_auto:
             flags |= _ffi.STEP_AUTORESET
