@@ -39,6 +39,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INC}", SRC,
            "-o", LIB + ".tmp"]
+    cmd += os.environ.get("W2A_CXXFLAGS", "").split()  # e.g. -DLANES=8 for kernel-geometry A/B runs
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -28,12 +28,52 @@
 
 #include "w2a.h"
 
-#define LANES 8
+#ifndef LANES
+#define LANES 4  // lanes per env: 8, 4, 2 or 1 (A/B-tested on MI355X)
+#endif
 #define ROWF 32
+#define QUADS (ROWF / 4 / LANES)  // float4 per lane per 32-float row
 #define BLOCK 256
 #define ENVS_PER_BLOCK (BLOCK / LANES)
 #define ENVS_PER_WAVE (64 / LANES)
 #define HDR_BYTES 256
+#ifndef W2A_NT_OBS
+#define W2A_NT_OBS 1  // observation rows leave with non-temporal stores (they are not re-read by the env)
+#endif
+#ifndef W2A_NT_STATE
+#define W2A_NT_STATE 0  // A/B: non-temporal loads/stores for the streamed per-env state, actions, reward, done
+#endif
+#ifndef W2A_NT_W
+#define W2A_NT_W 0      // A/B: non-temporal loads for the gathered coefficient rows
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_state(const uint4 *p) {
+#if W2A_NT_STATE
+  v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_state(uint4 *p, uint4 v) {
+#if W2A_NT_STATE
+  v4u w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<v4u *>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ float4 ld_w(const float4 *p) {
+#if W2A_NT_W
+  v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+#define RT_QUAD 6    // float4 index of the run-time slots 24..27
+#define GATE_QUAD 7  // float4 index holding the gate copy (slot 30 = .z)
 
 // ----------------------------------------------------------------------------------------
 // packed state
@@ -137,17 +177,17 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 // all-reduce (sum) over the 8 lanes of a group; every lane ends with the total
 __device__ __forceinline__ double group_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
-  v += dpp_f64<0x141>(v);  // row_half_mirror      : lane -> 7 - lane (other quad of the group)
+  if (LANES >= 2) v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  if (LANES >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  if (LANES >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror      : lane -> 7 - lane (other quad of the group)
   return v;
 }
 
 __device__ __forceinline__ float sigmoid_f32(float z) {
   // 1/(1+exp(-z)); exp(-z) overflows to +inf for z << 0 which gives exactly 0, and z = -inf
   // (closed effectiveness gate) also gives exactly 0.
-  float e = __expf(-z);
-  return __frcp_rn(1.0f + e);
+  float e = __expf(-z);                      // v_mul + v_exp_f32
+  return __builtin_amdgcn_rcpf(1.0f + e);    // v_rcp_f32 (1 ulp); rcp(+inf) = 0
 }
 
 // ----------------------------------------------------------------------------------------
@@ -199,17 +239,20 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
 // ----------------------------------------------------------------------------------------
 // observation tile: wave-level transpose through LDS, 16-B coalesced stores
 // ----------------------------------------------------------------------------------------
-// x        : this lane's 4 row floats (slots 4l..4l+3), run-time fields already patched
+// x        : this lane's QUADS float4 of the row (slots 4*(l*QUADS+q)..), run-time fields already patched
 // so       : obs column of each of those slots (-1 = not part of the observation)
 // write_me : this env's row must be written (false -> keep what is in memory)
 __device__ __forceinline__ void store_obs_tile(float *__restrict__ obs, float *tile, int64_t wave_env0, int64_t n,
-                                               int n_obs, int lane, int grp, int l, float4 x, int4 so,
+                                               int n_obs, int lane, int grp, const float4 *x, const int4 *so,
                                                bool write_me) {
   float *row = tile + grp * n_obs;
-  if (so.x >= 0) row[so.x] = x.x;
-  if (so.y >= 0) row[so.y] = x.y;
-  if (so.z >= 0) row[so.z] = x.z;
-  if (so.w >= 0) row[so.w] = x.w;
+#pragma unroll
+  for (int q = 0; q < QUADS; ++q) {
+    if (so[q].x >= 0) row[so[q].x] = x[q].x;
+    if (so[q].y >= 0) row[so[q].y] = x[q].y;
+    if (so[q].z >= 0) row[so[q].z] = x[q].z;
+    if (so[q].w >= 0) row[so[q].w] = x[q].w;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -217,10 +260,18 @@ __device__ __forceinline__ void store_obs_tile(float *__restrict__ obs, float *t
   const bool all_write = __all(write_me || (wave_env0 + grp >= n));
   float *dst = obs + wave_env0 * n_obs;
   if (full && all_write) {
-    const int chunks = (ENVS_PER_WAVE * n_obs) >> 2;  // 8*n_obs floats is a multiple of 4
-    if (lane < chunks) {
-      float4 v = reinterpret_cast<const float4 *>(tile)[lane];
-      reinterpret_cast<float4 *>(dst)[lane] = v;
+    const int chunks = (ENVS_PER_WAVE * n_obs) >> 2;  // ENVS_PER_WAVE*n_obs floats is a multiple of 4
+#pragma unroll
+    for (int c0 = 0; c0 < (ENVS_PER_WAVE * ROWF) / 4; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < chunks) {
+        v4f v = reinterpret_cast<const v4f *>(tile)[c];
+#if W2A_NT_OBS
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(dst) + c);
+#else
+        reinterpret_cast<v4f *>(dst)[c] = v;
+#endif
+      }
     }
   } else {
     // ragged tail or some env of the wave keeps its stale row: element-wise, masked
@@ -260,16 +311,16 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int l = tid & (LANES - 1);
-  const int grp = lane >> 3;
-  const int64_t wave_env0 = (int64_t)blockIdx.x * ENVS_PER_BLOCK + wave * ENVS_PER_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & (LANES - 1);
+  const int grp = lane / LANES;
+  const int64_t wave_env0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
-  const int64_t e = valid ? env : (a.n - 1);  // clamp: inactive groups shadow the last env, never store
+  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: inactive groups shadow the last env, never store
 
-  const uint4 cold = a.cold[e];
-  const uint4 hot = a.hot[e];
+  const uint4 cold = ld_state(a.cold + e);
+  const uint4 hot = ld_state(a.hot + e);
   int32_t act;
   if (a.act_dtype == W2A_ACT_I32) act = reinterpret_cast<const int32_t *>(a.actions)[e];
   else if (a.act_dtype == W2A_ACT_I64) act = (int32_t) reinterpret_cast<const int64_t *>(a.actions)[e];
@@ -288,26 +339,32 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
   const uint32_t used2 = used + actual;
   const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
 
-  // gathers: feature row of day t (pre-increment, Q6) and the env's coefficients
+  // gathers: feature row of day t (pre-increment, Q6) and the env's coefficients. Offsets are 32-bit
+  // (table sizes are validated in w2a_create) so the loads use the scalar-base + vgpr-offset form.
   const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
-  const size_t day_row = (size_t)t * rows_per_day + cold.x;
+  const uint32_t day_row = t * rows_per_day + cold.x;
   const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
-  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (WRITE_OBS || !TABLE) x = a.tb.X[day_row * (ROWF / 4) + l];
-  const int4 so = reinterpret_cast<const int4 *>(a.slot_obs)[l];
-  // env.py:190-193 run-time fields (slots 24..27 = lane 6)
+  float4 x[QUADS];
+  int4 so[QUADS];
+#pragma unroll
+  for (int q = 0; q < QUADS; ++q) {
+    x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WRITE_OBS || !TABLE) x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
+    if (WRITE_OBS) so[q] = reinterpret_cast<const int4 *>(a.slot_obs)[l * QUADS + q];
+  }
+  // env.py:190-193 run-time fields (slots 24..27)
   const float f_lag1 = (t > 0) ? (float)actual : 0.0f;   // alert_lag1: today's action for t>0 (Q3)
   const float f_streak = (float)streak;                  // streak before today's action (Q4)
   const float f_rem = (float)(budget - (int32_t)used2);  // remaining_budget
   const float f_a2w = (float)__popc(hist2);              // agent's 14-day count ('alert_2wks', Q1)
-  if (l == 6) x = make_float4(f_lag1, f_streak, f_rem, f_a2w);
+  if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(f_lag1, f_streak, f_rem, f_a2w);
   double zb, ze;
   if (TABLE) {
     // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
     // add the four run-time terms. Every lane of the group computes the same value (broadcast loads).
-    const double2 lv = a.tb.L[day_row * (size_t)a.tb.n_samples + W_SAMPLE(cold.y)];
-    const float4 qb = a.tb.Wendo[(size_t)wrow * 2];
-    const float4 qe = a.tb.Wendo[(size_t)wrow * 2 + 1];
+    const double2 lv = a.tb.L[(size_t)day_row * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y)];
+    const float4 qb = a.tb.Wendo[wrow * 2];
+    const float4 qe = a.tb.Wendo[wrow * 2 + 1];
     zb = fma((double)f_lag1, (double)qb.x, lv.x);
     zb = fma((double)f_streak, (double)qb.y, zb);
     zb = fma((double)f_rem, (double)qb.z, zb);
@@ -317,21 +374,31 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
     ze = fma((double)f_rem, (double)qe.z, ze);
     ze = fma((double)f_a2w, (double)qe.w, ze);
   } else {
-    const float4 *wp = a.tb.W + (size_t)wrow * (2 * ROWF / 4) + l;
-    const float4 wb = wp[0];
-    const float4 we = wp[ROWF / 4];
+    const float4 *wp = a.tb.W + wrow * (2 * ROWF / 4) + l * QUADS;
+    float4 wb[QUADS], we[QUADS];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+      wb[q] = ld_w(wp + q);
+      we[q] = ld_w(wp + ROWF / 4 + q);
+    }
     // env.py:207-217: two 28-term dot products, fp64 accumulation
-    zb = (double)x.x * (double)wb.x;
-    zb = fma((double)x.y, (double)wb.y, zb);
-    zb = fma((double)x.z, (double)wb.z, zb);
-    zb = fma((double)x.w, (double)wb.w, zb);
-    ze = (double)x.x * (double)we.x;
-    ze = fma((double)x.y, (double)we.y, ze);
-    ze = fma((double)x.z, (double)we.z, ze);
-    ze = fma((double)x.w, (double)we.w, ze);
-    // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 (lane 7, .z) holds a copy of heat_qi with a
-    // zero coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
-    if (l == 7 && !(x.z > 0.5f)) ze = -__builtin_inf();
+    zb = 0.0;
+    ze = 0.0;
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+      const double x0 = (double)x[q].x, x1 = (double)x[q].y, x2 = (double)x[q].z, x3 = (double)x[q].w;
+      zb = fma(x0, (double)wb[q].x, zb);
+      zb = fma(x1, (double)wb[q].y, zb);
+      zb = fma(x2, (double)wb[q].z, zb);
+      zb = fma(x3, (double)wb[q].w, zb);
+      ze = fma(x0, (double)we[q].x, ze);
+      ze = fma(x1, (double)we[q].y, ze);
+      ze = fma(x2, (double)we[q].z, ze);
+      ze = fma(x3, (double)we[q].w, ze);
+    }
+    // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds a copy of heat_qi with a zero
+    // coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
+    if (l == GATE_QUAD / QUADS && !(x[GATE_QUAD % QUADS].z > 0.5f)) ze = -__builtin_inf();
     zb = group_sum(zb);
     ze = group_sum(ze);
   }
@@ -341,20 +408,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
   const float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
 
   const bool done = (t + 1 >= ndays);  // env.py:256
-  uint32_t t2 = t, streak2 = streak, fin = 0;
-  if (!done) {
-    t2 = t + 1;
-    streak2 = actual ? streak + 1 : 0;  // env.py:260
-  } else {
-    fin = 1;
-  }
-  float ret = __uint_as_float(hot.z) + r;
+  const uint32_t t2 = done ? t : t + 1;
+  const uint32_t streak2 = done ? streak : (actual ? streak + 1 : 0);  // env.py:260
+  const float ret = __uint_as_float(hot.z) + r;
 
-  uint4 hot2 = make_uint4(pack_d0(t2, used2, streak2, actual, atb), pack_d1(hist2, ndays, fin),
+  uint4 hot2 = make_uint4(pack_d0(t2, used2, streak2, actual, atb), pack_d1(hist2, ndays, done ? 1u : 0u),
                           __float_as_uint(ret), (uint32_t)budget);
   uint4 cold2 = cold;
   bool write_row = !done;
-  if (done && valid && l == 0 && a.last_return) a.last_return[e] = ret;
   if (AUTORESET) {
     if (done) {
       // same-step autoreset: draw the next episode, emit its first observation (env.py:162-181)
@@ -363,21 +424,30 @@ __global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
       cold2 = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
       hot2 = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
       if (WRITE_OBS) {
-        x = a.tb.X[(size_t)ep.ep_row * (ROWF / 4) + l];
-        if (l == 6) x = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[ep.ep_row * (ROWF / 4) + l * QUADS + q];
+        if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
       }
       write_row = true;
     }
   }
   if (valid && l == 0) {
-    a.hot[e] = hot2;
+    st_state(a.hot + e, hot2);
+#if W2A_NT_STATE
+    __builtin_nontemporal_store(r, a.reward + e);
+    __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), a.done + e);
+#else
     a.reward[e] = r;
     a.done[e] = done ? 1 : 0;
-    if (AUTORESET && done) a.cold[e] = cold2;
+#endif
+    if (done) {
+      if (a.last_return) a.last_return[e] = ret;
+      if (AUTORESET) a.cold[e] = cold2;
+    }
+    if (st_bits) atomicOr(a.status, (int)st_bits);
   }
-  if (st_bits && valid && l == 0) atomicOr(a.status, (int)st_bits);
   if (WRITE_OBS) {
-    store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, l, x, so, write_row);
+    store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, write_row);
   }
 }
 
@@ -404,13 +474,13 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int l = tid & (LANES - 1);
-  const int grp = lane >> 3;
-  const int64_t wave_env0 = (int64_t)blockIdx.x * ENVS_PER_BLOCK + wave * ENVS_PER_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & (LANES - 1);
+  const int grp = lane / LANES;
+  const int64_t wave_env0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
-  const int64_t e = valid ? env : (a.n - 1);
+  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
   const bool sel = a.mask ? (a.mask[e] != 0) : true;
   uint4 cold = a.cold[e];
   uint32_t bad = 0;
@@ -426,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     // the logit-table path needs coefficient column == the weather county's own column
     if (a.tb.weather_to_fips && a.tb.weather_to_fips[cw] != cc) bad |= 2;
     int32_t nd = a.tb.n_days[ep.ep_row];
-    if (nd <= 0) { nd = 1; bad = 1; }
+    if (nd <= 0) { nd = 1; bad |= 1; }
     ep.ndays = (uint32_t)nd;
     ep.budget = a.budget ? a.budget[e] : a.tb.B0[ep.ep_row];
     ep.sticky = (int32_t)cold.z;
@@ -434,16 +504,21 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
     bad = ep.bad;
   }
-  float4 x = a.tb.X[(size_t)ep.ep_row * (ROWF / 4) + l];  // day 0
-  if (l == 6) x = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
-  const int4 so = reinterpret_cast<const int4 *>(a.slot_obs)[l];
+  float4 x[QUADS];
+  int4 so[QUADS];
+#pragma unroll
+  for (int q = 0; q < QUADS; ++q) {
+    x[q] = a.tb.X[ep.ep_row * (ROWF / 4) + l * QUADS + q];  // day 0
+    so[q] = reinterpret_cast<const int4 *>(a.slot_obs)[l * QUADS + q];
+  }
+  if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
   if (valid && sel && l == 0) {
     a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
     a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
   }
-  if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, l, x, so, sel);
+  if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }
 
 __global__ void k_init_state(uint4 *cold, uint4 *hot, int64_t n) {
@@ -606,6 +681,9 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   if ((int64_t)t->S_w * t->Y > 0x7FFFFFFFll / 2 || (int64_t)t->S * t->n_samples > 0x7FFFFFFFll / 2 ||
       (int64_t)t->T * t->S_w * t->Y > 0x7FFFFFFFll)
     return fail(W2A_ERR_SCHEMA, "w2a_create: table too large for 32-bit row indices");
+  if ((int64_t)t->T * t->S_w * t->Y * (ROWF / 4) > 0x7FFFFFFFll || (int64_t)t->S * t->n_samples * (2 * ROWF / 4) > 0x7FFFFFFFll ||
+      num_envs > (1ll << 27))
+    return fail(W2A_ERR_SCHEMA, "w2a_create: tables / env count exceed the 32-bit offset range of the kernels");
   if (t->n_samples > (1 << SAMPLE_BITS) || t->S >= (1 << (32 - SAMPLE_BITS)))
     return fail(W2A_ERR_SCHEMA, "w2a_create: need n_samples <= 4096 and S < 2^20");
   if ((t->L != nullptr) != (t->Wendo != nullptr) || (t->L && !t->weather_to_fips))
