@@ -54,6 +54,10 @@ def parse():
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
+                   help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo = rehearsal of the multi-rank path with several ranks sharing one GPU")
     return p.parse_args()
 
 
@@ -112,9 +116,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    device = torch.device(f"cuda:{local}")
+    device = torch.device(f"cuda:{local % torch.cuda.device_count() if args.backend == 'gloo' else local}")
     torch.cuda.set_device(device)
-    wdist.init_from_env("nccl", device)
+    wdist.init_from_env(args.backend, device)
 
     wname, n_default, augment, rpath, desc = WORKLOADS[args.workload]
     n = args.num_envs or n_default
@@ -126,7 +130,7 @@ def main():
     if rpath == "table":
         dt.build_logit_table(timed=True)
     env = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, env_gid0=rank * n,
-                          write_obs=not args.no_obs, reward_path=rpath)
+                          write_obs=not args.no_obs, reward_path=rpath, episode_order=args.episode_order)
     gather = wdist.ReturnGatherer(n, device)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
@@ -183,7 +187,7 @@ def main():
             "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
                        "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
-                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath,
+                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath, "episode_order": args.episode_order,
                        "logit_table_build_ms": dt.logit_build_ms,
                        "logit_table_gb": None if dt.L is None else dt.L.numel() * 8 / 1e9,
                        "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},

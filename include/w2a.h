@@ -161,6 +161,19 @@ size_t w2a_wendo_bytes(const w2a_tables *tables);
 int w2a_build_logit_table(const w2a_tables *tables, void *L, size_t L_bytes, void *Wendo, size_t Wendo_bytes,
                           void *stream);
 
+/* episode_order="sorted" (no reference counterpart; opt-in): after a reset, relabel the envs so that env
+ * indices follow the coefficient row (by_weather_row = 0, row-gather path) or the (county, year, draw) logit
+ * row (by_weather_row = 1, table path). The multiset of episodes is unchanged -- only which env index holds
+ * which episode -- but neighbouring envs now share table lines, which the step kernel's gathers turn into
+ * L2 hits. The whole per-env record moves (episode tuple, budget, sticky budget, episode number).
+ * workspace: caller-owned, w2a_sort_workspace_bytes(num_envs) bytes, 256-B aligned. */
+size_t w2a_sort_workspace_bytes(int64_t num_envs);
+int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream);
+
+/* First observation (env.py:181) of every env from its packed state; valid right after a reset
+ * (t == 0 for every env, else W2A_ST_STEP_AFTER_DONE is raised). Used after w2a_sort_episodes. */
+int w2a_observe(w2a_env *env, float *obs, void *stream);
+
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
 

@@ -251,8 +251,8 @@ def test_device_rng_reset_matches_restatement(dev):
     env.close()
 
 
-@pytest.mark.parametrize("path", ["gather", "table"])
-def test_same_step_autoreset_and_shard_invariance(dev, path):
+@pytest.mark.parametrize("path,lockstep", [("gather", True), ("gather", False), ("table", True), ("table", False)])
+def test_same_step_autoreset_and_shard_invariance(dev, path, lockstep):
     """Lock-step autoreset on the device: after 153 steps every env restarts inside the same
     call; final returns are reported; and two half-size shards keyed by global env id give the
     same trajectories as one full-size env (multi-GPU correctness by construction)."""
@@ -261,10 +261,13 @@ def test_same_step_autoreset_and_shard_invariance(dev, path):
     sd = synth.make_synth("linear", n_fips=32, years=[2006, 2007], n_samples=6, seed=5)
     ct = tables.compile_from_synth(sd)
     n = 2048 + 40
-    full = HeatAlertVecEnv(n, tables=ct, device=dev, reward_path=path)
+    # `full` is driven as requested; the shards use the other autoreset implementation (host-counted lock step
+    # vs in-kernel), so the comparison also proves the two implementations draw identical episodes
+    full = HeatAlertVecEnv(n, tables=ct, device=dev, reward_path=path, lockstep=lockstep)
+    assert full._lockstep == lockstep
     h = n // 2
-    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0, reward_path=path),
-             HeatAlertVecEnv(n - h, tables=ct, device=dev, env_gid0=h, reward_path="gather")]
+    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0, reward_path=path, lockstep=not lockstep),
+             HeatAlertVecEnv(n - h, tables=ct, device=dev, env_gid0=h, reward_path="gather", lockstep=lockstep)]
     o_full, _ = full.reset(seed=77)
     o_parts = [p.reset(seed=77)[0] for p in parts]
     assert torch.equal(o_full, torch.cat(o_parts))
@@ -295,6 +298,42 @@ def test_same_step_autoreset_and_shard_invariance(dev, path):
     assert full.check_status() == 0
     for e in [full] + parts:
         e.close()
+
+
+def test_masked_reset_leaves_lockstep_and_autoresets_in_kernel(dev):
+    """A partial reset breaks lock step: the env switches to the in-kernel autoreset and envs then finish at
+    different times, each restarting on its own terminal step."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=2)
+    ct = tables.compile_from_synth(sd)
+    n = 500
+    env = HeatAlertVecEnv(n, tables=ct, device=dev)
+    assert env._lockstep
+    env.reset(seed=3)
+    a = torch.zeros(n, dtype=torch.int32, device=dev)
+    for _ in range(100):
+        env.step(a)
+    mask = np.zeros(n, bool)
+    mask[: n // 2] = True
+    env.reset(seed=3, options={"mask": mask})
+    assert not env._lockstep
+    first, second = [], []
+    for k in range(153):
+        _, _, d, _, _ = env.step(a)
+        d = d.cpu().numpy()
+        if d[n // 2:].any():
+            assert d[n // 2:].all() and not d[: n // 2].any()
+            second.append(k)
+        if d[: n // 2].any():
+            assert d[: n // 2].all() and not d[n // 2:].any()
+            first.append(k)
+    assert second == [52] and first == [152]
+    st = env.state()
+    assert (st["episode_no"][: n // 2] == 2).all() and (st["episode_no"][n // 2:] == 1).all()
+    assert (st["t"][: n // 2] == 0).all() and (st["t"][n // 2:] == 100).all()
+    assert env.check_status() == 0
+    env.close()
 
 
 def test_masked_reset_bad_inputs_and_reward_only(dev, mini):
@@ -336,3 +375,50 @@ def test_masked_reset_bad_inputs_and_reward_only(dev, mini):
         assert torch.equal(ra, rb)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("path", ["gather", "table"])
+def test_sorted_episode_order_is_a_relabelling(dev, path):
+    """episode_order='sorted': same multiset of episodes as the iid order for the same seed, env indices
+    follow the table rows, stepping (incl. the host-driven lock-step autoreset) matches the oracle."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=48, years=[2006, 2007, 2008], n_samples=12, seed=9, extra_confounder_fips=4)
+    ct = tables.compile_from_synth(sd)
+    n, aug = 3000 + 17, path == "gather"
+    kw = dict(tables=ct, device=dev, reward_path=path, similar_climate_counties=aug)
+    iid = HeatAlertVecEnv(n, **kw)
+    srt = HeatAlertVecEnv(n, episode_order="sorted", **kw)
+    iid.reset(seed=5)
+    obs, _ = srt.reset(seed=5)
+    keys = ("county_w", "year_i", "coef_col", "sample", "budget", "sticky_budget", "episode_no")
+    a = np.stack([iid.state()[k].cpu().numpy() for k in keys], 1)
+    b = np.stack([srt.state()[k].cpu().numpy() for k in keys], 1)
+    assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])  # same multiset of records
+    if path == "gather":
+        k = (b[:, 2].astype(np.int64) << 12 | b[:, 3]) << 32 | (b[:, 0] * ct.Y + b[:, 1])
+    else:
+        k = ((b[:, 0] * ct.Y + b[:, 1]).astype(np.int64) << 12) | b[:, 3]
+    assert (np.diff(k) >= 0).all() and len(np.unique(k)) > n // 4
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    rng = np.random.default_rng(0)
+    for episode in range(2):
+        st = {kk: v.cpu().numpy() for kk, v in srt.state().items()}
+        assert (st["episode_no"] == episode).all() and (st["t"] == 0).all()
+        obs_o = V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+        np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        ret = np.zeros(n)
+        for t in range(153):
+            act = (rng.random(n) < 0.2).astype(np.int32)
+            obs, r, done, _, info = srt.step(torch.as_tensor(act, device=dev))
+            obs_o, r_o, done_o, _ = V.step(act)
+            assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+            np.testing.assert_array_equal(done.cpu().numpy(), done_o)
+            ret += r_o
+            if t < 152:
+                np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        assert done.all()
+        np.testing.assert_allclose(info["final_return"].cpu().numpy(), ret, rtol=2e-5)
+    assert srt.check_status() == 0
+    iid.close()
+    srt.close()

@@ -21,6 +21,7 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
+    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe",
 ]
 
 
@@ -97,6 +98,12 @@ def load(build_if_missing: bool = True):
     lib.w2a_wendo_bytes.argtypes = [C.POINTER(Tables)]
     lib.w2a_build_logit_table.restype = C.c_int
     lib.w2a_build_logit_table.argtypes = [C.POINTER(Tables), vp, C.c_size_t, vp, C.c_size_t, vp]
+    lib.w2a_sort_workspace_bytes.restype = C.c_size_t
+    lib.w2a_sort_workspace_bytes.argtypes = [i64]
+    lib.w2a_sort_episodes.restype = C.c_int
+    lib.w2a_sort_episodes.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
+    lib.w2a_observe.restype = C.c_int
+    lib.w2a_observe.argtypes = [vp, vp, vp]
     if lib.w2a_abi_version() != ABI_VERSION:
         raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib

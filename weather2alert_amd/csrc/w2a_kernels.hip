@@ -22,6 +22,7 @@
 // No fallback path exists: if this library is missing the Python package fails to import.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -46,6 +47,19 @@
 #ifndef W2A_NT_W
 #define W2A_NT_W 0      // A/B: non-temporal loads for the gathered coefficient rows
 #endif
+#ifndef W2A_XCD_SWIZZLE
+#define W2A_XCD_SWIZZLE 1  // consecutive env tiles on the same XCD (workgroups are dealt round-robin over 8 XCDs)
+#endif
+// Logical tile of a workgroup. With the swizzle, XCD k (blockIdx % 8 == k, observed placement; only speed
+// depends on it) walks the k-th contiguous eighth of the env range, so neighbouring envs share an L2: partial
+// output lines (reward, done) merge there, and with episode_order="sorted" each XCD touches one eighth of W / L.
+__device__ __forceinline__ uint32_t logical_block(uint32_t b, uint32_t per_xcd) {
+#if W2A_XCD_SWIZZLE
+  return (b & 7u) * per_xcd + (b >> 3);
+#else
+  return b;
+#endif
+}
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_state(const uint4 *p) {
@@ -306,15 +320,22 @@ struct StepArgs {
   int32_t act_dtype;
 };
 
+#ifndef W2A_MIN_WAVES
+#define W2A_MIN_WAVES 8  // waves/SIMD the plain step variants are compiled for (<= 64 VGPRs): the kernel is
+#endif                   // latency-bound and measured faster at full occupancy
+// The in-kernel autoreset variants carry the episode draw and would spill at 64 VGPRs (measured 1.4x slower),
+// so they keep the compiler's own allocation; lock-step batches use the plain variant + k_reset instead.
 template <bool AUTORESET, bool WRITE_OBS, bool TABLE>
-__global__ __launch_bounds__(BLOCK) void k_step(const StepArgs a) {
+__global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = lane & (LANES - 1);
   const int grp = lane / LANES;
-  const int64_t wave_env0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
+  const int64_t wave_env0 = ((int64_t)lb * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no barrier is used below
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: inactive groups shadow the last env, never store
@@ -477,7 +498,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = lane & (LANES - 1);
   const int grp = lane / LANES;
-  const int64_t wave_env0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);
+  const int64_t wave_env0 = ((int64_t)lb * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  if (wave_env0 >= a.n) return;
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
@@ -485,7 +508,13 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   uint4 cold = a.cold[e];
   uint32_t bad = 0;
   Episode ep;
-  if (a.from_tuples) {
+  if (a.from_tuples == 2) {
+    // observe only (w2a_observe): first observation of an already reset env, state untouched
+    const uint4 hot = a.hot[e];
+    ep.ep_row = cold.x;
+    ep.budget = (int32_t)hot.w;
+    if (D0_T(hot.x) != 0) bad = 4;
+  } else if (a.from_tuples) {
     int32_t cw = a.county_w[e], yi = a.year_i[e], cc = a.coef_col[e], sm = a.sample[e];
     if (cw < 0 || cw >= a.tb.S_w) { cw = 0; bad = 1; }
     if (yi < 0 || yi >= a.tb.Y) { yi = 0; bad = 1; }
@@ -513,10 +542,13 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   }
   if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
   if (valid && sel && l == 0) {
-    a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
-    a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
+    if (a.from_tuples != 2) {
+      a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
+      a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
+    }
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
+    if (bad & 4) atomicOr(a.status, (int)W2A_ST_STEP_AFTER_DONE);
   }
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }
@@ -651,6 +683,26 @@ __global__ void k_pack_wendo(const float4 *W, float4 *Wendo, int64_t rows) {
 }
 
 // ----------------------------------------------------------------------------------------
+// episode_order="sorted": relabel envs so that neighbours share coefficient / logit rows
+// ----------------------------------------------------------------------------------------
+__global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, int64_t n, int by_weather_row) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4 c = cold[i];
+  // gather path: coefficient row (column, draw) major, weather row minor; table path: weather row, then draw
+  keys[i] = by_weather_row ? (((uint64_t)c.x << SAMPLE_BITS) | W_SAMPLE(c.y)) : (((uint64_t)c.y << 32) | c.x);
+  idx[i] = (uint32_t)i;
+}
+__global__ void k_permute_state(const uint4 *cold, const uint4 *hot, const uint32_t *idx, uint4 *cold_o, uint4 *hot_o,
+                                int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t j = idx[i];
+  cold_o[i] = cold[j];
+  hot_o[i] = hot[j];
+}
+
+// ----------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------
 #define HIP_TRY(expr)                                                   \
@@ -733,7 +785,11 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
 
 void w2a_destroy(w2a_env *env) { delete env; }
 
-static unsigned grid_for(int64_t n) { return (unsigned)((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK); }
+// tiles of ENVS_PER_BLOCK envs, rounded up to a multiple of 8 workgroups (one share per XCD, see logical_block)
+static unsigned grid_for(int64_t n) {
+  int64_t tiles = (n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+  return (unsigned)(((tiles + 7) / 8) * 8);
+}
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.cold = env->cold; a.hot = env->hot;
@@ -856,6 +912,53 @@ int w2a_build_logit_table(const w2a_tables *t, void *L, size_t L_bytes, void *We
                      reinterpret_cast<const float4 *>(t->W), reinterpret_cast<float4 *>(Wendo), rows);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t cub_sort_bytes(int64_t n) {
+  size_t b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+  return b;
+}
+
+size_t w2a_sort_workspace_bytes(int64_t num_envs) {
+  if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
+  size_t n = (size_t)num_envs;
+  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) * 2 + align256(cub_sort_bytes(num_envs));
+}
+
+int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_sort_episodes: NULL argument");
+  if (workspace_bytes < w2a_sort_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace too small");
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace must be 256-B aligned");
+  const size_t n = (size_t)env->n;
+  char *p = (char *)workspace;
+  uint64_t *k_in = (uint64_t *)p;  p += align256(8 * n);
+  uint64_t *k_out = (uint64_t *)p; p += align256(8 * n);
+  uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
+  uint32_t *i_out = (uint32_t *)p; p += align256(4 * n);
+  uint4 *cold_t = (uint4 *)p;      p += align256(16 * n);
+  uint4 *hot_t = (uint4 *)p;       p += align256(16 * n);
+  size_t cub_bytes = cub_sort_bytes(env->n);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->cold, k_in, i_in, env->n, by_weather_row);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
+  hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->cold, env->hot, i_out, cold_t, hot_t, env->n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(env->cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(env->hot, hot_t, 16 * n, hipMemcpyDeviceToDevice, s));
+  return W2A_OK;
+}
+
+int w2a_observe(w2a_env *env, float *obs, void *stream) {
+  if (!env || !obs) return fail(W2A_ERR_ARG, "w2a_observe: NULL argument");
+  ResetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.obs = obs; a.from_tuples = 2;
+  return launch_reset(env, a, stream);
 }
 
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {

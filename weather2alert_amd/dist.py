@@ -49,6 +49,11 @@ class ReturnGatherer:
     def gather(self, local_returns: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             self.out.copy_(local_returns)
+        elif dist.get_backend() == "gloo" and local_returns.is_cuda:
+            # rehearsal path (several ranks on one GPU / no RCCL): gloo has no CUDA all-gather, stage on the host
+            tmp = torch.empty(self.out.shape, dtype=self.out.dtype)
+            dist.all_gather_into_tensor(tmp, local_returns.cpu().contiguous())
+            self.out.copy_(tmp)
         else:
             dist.all_gather_into_tensor(self.out, local_returns.contiguous())
         return self.out
@@ -57,7 +62,12 @@ class ReturnGatherer:
         """Scalar mean return over all shards (cheaper than the gather when only this is needed)."""
         s = local_returns.double().sum().reshape(1)
         if self.world > 1:
-            dist.all_reduce(s)
+            if dist.get_backend() == "gloo" and s.is_cuda:
+                c = s.cpu()
+                dist.all_reduce(c)
+                s = c.to(s.device)
+            else:
+                dist.all_reduce(s)
         return s / (self.world * self.n_local)
 
 
@@ -69,6 +79,6 @@ def barrier():
 def max_over_ranks(x: float, device) -> float:
     if not dist.is_initialized():
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

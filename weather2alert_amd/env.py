@@ -45,6 +45,18 @@ class HeatAlertVecEnv:
                          by a grouped fp64-MFMA GEMM (DeviceTables.build_logit_table) -- less memory traffic
                          per step, but only for episodes whose coefficients are the weather county's own,
                          i.e. without similar_climate_counties; "auto": table unless augmentation is on.
+    episode_order        "iid" (default): env i keeps its own independent draws, like N reference envs;
+                         "sorted": after every (lock-step) reset the envs are relabelled so that env indices
+                         follow the coefficient / logit-table row. The batch holds exactly the same multiset of
+                         episodes, only which index holds which episode changes (env identity is not preserved
+                         across episodes); neighbouring envs then share table lines and the step kernel's
+                         gathers become L2 hits. Needs seed_mode="device" and a uniform episode length.
+    lockstep             how same-step autoreset is driven in device seed mode. True: every episode has the same
+                         length and the whole batch resets together, so the host counts steps and launches the
+                         reset kernel after the terminal step (the step kernel then runs its leaner, full-occupancy
+                         variant). False: each env restarts inside the step kernel whenever it finishes (needed
+                         after partial resets). None (default): True when the tables allow it; falls back to
+                         False by itself after a masked reset.
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -68,6 +80,8 @@ class HeatAlertVecEnv:
         env_gid0: int = 0,
         write_obs: bool = True,
         reward_path: Literal["gather", "table", "auto"] = "gather",
+        episode_order: Literal["iid", "sorted"] = "iid",
+        lockstep: bool | None = None,
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -99,6 +113,11 @@ class HeatAlertVecEnv:
             raise ValueError("reward_path='table' cannot serve similar_climate_counties=True (Q8 pairs a county's "
                              "weather with another county's coefficients); use 'gather'")
         self.reward_path = reward_path
+        if episode_order not in ("iid", "sorted"):
+            raise ValueError(f"episode_order {episode_order!r}")
+        if episode_order == "sorted" and seed_mode != "device":
+            raise ValueError("episode_order='sorted' needs seed_mode='device'")
+        self.episode_order = episode_order
         if reward_path == "table":
             self.dtables.build_logit_table()
         ct = self.ct = self.dtables.ct
@@ -127,6 +146,31 @@ class HeatAlertVecEnv:
             _ffi.check(self._lib.w2a_create(C.byref(self.dtables.struct), n, self.env_gid0, self._state.data_ptr(),
                                             nbytes, self._status.data_ptr(), C.byref(h)), "w2a_create")
         self._h = h
+        # hot-path constants (step() is called millions of times: no per-call attribute chains)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._obs_ptr = self._obs.data_ptr() if self.write_obs else None
+        self._rew_ptr, self._done_ptr = self._reward.data_ptr(), self._done.data_ptr()
+        self._fr_ptr = self._final_return.data_ptr()
+        self._done_bool = self._done.view(torch.bool)
+        self._sort_ws = None
+        nd = np.unique(ct.n_days)
+        uniform = len(nd) == 1 and nd[0] > 0
+        if episode_order == "sorted":
+            if not uniform:
+                raise ValueError("episode_order='sorted' needs one episode length for every (county, year)")
+            if lockstep is False:
+                raise ValueError("episode_order='sorted' implies lockstep")
+            with torch.cuda.device(dev):
+                self._sort_ws = torch.empty(self._lib.w2a_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        if lockstep and not uniform:
+            raise ValueError("lockstep=True needs one episode length for every (county, year)")
+        self._episode_len = int(nd[0]) if uniform else 0
+        self._lockstep = bool(uniform and self.seed_mode == "device" and lockstep is not False)
+        self._steps_in_episode = 0
+        self._reset_cfg = None
+        self._set_step_mode()
+        self._w2a_step = self._lib.w2a_step
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         self._sticky = [budget] * n  # host mirror of self.budget per env (numpy_parity mode, Q9)
         self._needs_reset = True
         self._flags = 0
@@ -134,7 +178,17 @@ class HeatAlertVecEnv:
         self._episode_seed = 0
 
     # ------------------------------------------------------------------ plumbing
+    def _set_step_mode(self):
+        """in-kernel autoreset only when the batch is not in lock step (device seed mode)."""
+        self._dev_auto = self.autoreset == "same_step" and self.seed_mode == "device" and not self._lockstep
+        self._host_auto = self.autoreset == "same_step" and self.seed_mode == "device" and self._lockstep
+        self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
+                            (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
+                            (_ffi.STEP_AUTORESET if self._dev_auto else 0))
+
     def _stream(self):
+        if self._raw_stream is not None:
+            return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def close(self):
@@ -195,8 +249,18 @@ class HeatAlertVecEnv:
             mask_t = torch.as_tensor(np.asarray(mask), dtype=torch.uint8, device=self.device)
         obs_ptr = self._obs.data_ptr() if self.write_obs else None
         self._last_opts = {k: v for k, v in options.items() if k not in ("mask", "episodes")}
+        if self._lockstep and (mask is not None or "episodes" in options):
+            if self.episode_order == "sorted":
+                raise ValueError("episode_order='sorted' resets the whole batch with the device RNG only")
+            self._lockstep = False  # partial / injected resets: envs finish at different times from now on
+            self._set_step_mode()
         if "episodes" in options:
             self._reset_tuples(options["episodes"], mask_t, obs_ptr)
+            if self.seed_mode == "device" and self.autoreset == "same_step":
+                # later episodes of these envs come from the device RNG (in-kernel autoreset)
+                self._reset_cfg = self._device_cfg(seed, self._last_opts)
+                with torch.cuda.device(self.device):
+                    _ffi.check(self._lib.w2a_set_autoreset(self._h, *self._reset_cfg), "w2a_set_autoreset")
         elif self.seed_mode == "numpy_parity":
             self._reset_numpy_parity(seed, options, mask, mask_t, obs_ptr)
         else:
@@ -327,11 +391,29 @@ class HeatAlertVecEnv:
         cfg = self._device_cfg(seed, options)
         if cfg[2] and (ct.sim_cnt <= 0).any() and cfg[1] < 0:
             raise KeyError("a fips_list county is missing from the confounders table (datautils.py:123)")
+        if self.episode_order == "sorted" and mask_t is not None:
+            raise ValueError("episode_order='sorted' resets the whole batch; masks are not supported")
+        self._reset_cfg = cfg
+        self._launch_device_reset(mask_t, obs_ptr)
         with torch.cuda.device(self.device):
-            _ffi.check(self._lib.w2a_reset_device_rng(self._h, *cfg, None if mask_t is None else mask_t.data_ptr(),
-                                                      obs_ptr, self._stream()), "w2a_reset_device_rng")
             _ffi.check(self._lib.w2a_set_autoreset(self._h, *cfg), "w2a_set_autoreset")
         self._keep = (mask_t,)
+
+    def _launch_device_reset(self, mask_t, obs_ptr):
+        """Device-RNG reset of the batch (next episode number per env); in sorted mode followed by the
+        relabelling sort and the observation pass. Asynchronous, no host sync."""
+        lib, st = self._lib, self._stream()
+        srt = self.episode_order == "sorted"
+        with torch.cuda.device(self.device):
+            _ffi.check(lib.w2a_reset_device_rng(self._h, *self._reset_cfg, None if mask_t is None else
+                                                mask_t.data_ptr(), None if srt else obs_ptr, st),
+                       "w2a_reset_device_rng")
+            if srt:
+                _ffi.check(lib.w2a_sort_episodes(self._h, int(self.reward_path == "table"), self._sort_ws.data_ptr(),
+                                                 self._sort_ws.numel(), st), "w2a_sort_episodes")
+                if obs_ptr is not None:
+                    _ffi.check(lib.w2a_observe(self._h, obs_ptr, st), "w2a_observe")
+        self._steps_in_episode = 0
 
     # ------------------------------------------------------------------ step
     def step(self, actions):
@@ -339,6 +421,27 @@ class HeatAlertVecEnv:
         tensors that are reused by the next call (clone them to keep a copy)."""
         if self._needs_reset:
             raise RuntimeError("call reset() before step()")
+        if (type(actions) is not torch.Tensor or actions.device != self.device or actions.dtype not in _ACT_CODES
+                or actions.numel() != self.num_envs or not actions.is_contiguous()):
+            actions = self._coerce_actions(actions)
+        rc = self._w2a_step(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype], self._obs_ptr, self._rew_ptr,
+                            self._done_ptr, self._fr_ptr, self._step_flags, self._stream())
+        if rc != 0:
+            _ffi.check(rc, "w2a_step")
+        self._keep_act = actions
+        done = self._done_bool
+        if self._host_auto:  # lock step: the host counts days and launches the reset after the terminal step
+            self._steps_in_episode += 1
+            if self._steps_in_episode == self._episode_len:
+                self._launch_device_reset(None, self._obs_ptr)
+        elif self.autoreset == "same_step" and not self._dev_auto:
+            d = done.cpu().numpy()
+            if d.any():  # host-side autoreset (numpy_parity): fresh global-RNG seeds like reset(seed=None)
+                self._reset_numpy_parity(None, self._last_opts, d, torch.as_tensor(d.astype(np.uint8),
+                                         device=self.device), self._obs_ptr)
+        return self._obs, self._reward, done, self._truncated, _LazyInfo(self)
+
+    def _coerce_actions(self, actions):
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions), device=self.device)
         elif actions.device != self.device:
@@ -347,27 +450,7 @@ class HeatAlertVecEnv:
             actions = actions.to(torch.int32)
         if actions.numel() != self.num_envs:
             raise ValueError(f"expected {self.num_envs} actions, got {actions.numel()}")
-        if not actions.is_contiguous():
-            actions = actions.contiguous()
-        flags = 0 if self.write_obs else _ffi.STEP_NO_OBS
-        if self.reward_path == "table":
-            flags |= _ffi.STEP_TABLE
-        dev_auto = self.autoreset == "same_step" and self.seed_mode == "device"
-        if dev_auto:
-            flags |= _ffi.STEP_AUTORESET
-        rc = self._lib.w2a_step(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype],
-                                self._obs.data_ptr() if self.write_obs else None, self._reward.data_ptr(),
-                                self._done.data_ptr(), self._final_return.data_ptr(), flags, self._stream())
-        if rc != 0:
-            _ffi.check(rc, "w2a_step")
-        self._keep_act = actions
-        done = self._done.view(torch.bool)
-        if self.autoreset == "same_step" and not dev_auto:
-            d = done.cpu().numpy()
-            if d.any():  # host-side autoreset (numpy_parity): fresh global-RNG seeds like reset(seed=None)
-                self._reset_numpy_parity(None, self._last_opts, d, torch.as_tensor(d.astype(np.uint8),
-                                         device=self.device), self._obs.data_ptr() if self.write_obs else None)
-        return self._obs, self._reward, done, self._truncated, self._info()
+        return actions.contiguous()
 
     def _info(self):
         return _LazyInfo(self)
