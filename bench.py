@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--graph", type=int, default=0,
+                   help="capture this many consecutive step() calls into one hipGraph and replay it (launch-bound "
+                        "small batches); the timed region still runs exactly --steps steps")
     p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
                    help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -130,7 +133,8 @@ def main():
     if rpath == "table":
         dt.build_logit_table(timed=True)
     env = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, env_gid0=rank * n,
-                          write_obs=not args.no_obs, reward_path=rpath, episode_order=args.episode_order)
+                          write_obs=not args.no_obs, reward_path=rpath, episode_order=args.episode_order,
+                          lockstep=False if args.graph else None)
     gather = wdist.ReturnGatherer(n, device)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
@@ -150,12 +154,35 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
+    graph = None
+    if args.graph:
+        # hipGraph of G consecutive steps (fixed action buffers); autoreset runs inside the kernel so that
+        # the captured work is identical for every replay
+        assert args.steps % args.graph == 0 and not env._host_auto, "--graph needs lockstep=False and steps % G == 0"
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            env.step(pool[0])
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            for i in range(args.graph):
+                env.step(pool[i & 15])
+        torch.cuda.synchronize()
     wdist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        one_step()
+    if graph is None:
+        for _ in range(args.steps):
+            one_step()
+    else:
+        for _ in range(args.steps // args.graph):
+            graph.replay()
+            before = stepno
+            stepno += args.graph
+            if stepno // T != before // T:
+                gather.gather(env._final_return)
     ev1.record()
     torch.cuda.synchronize()
     wdist.barrier()
@@ -187,7 +214,7 @@ def main():
             "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
                        "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
-                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath, "episode_order": args.episode_order,
+                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
                        "logit_table_build_ms": dt.logit_build_ms,
                        "logit_table_gb": None if dt.L is None else dt.L.numel() * 8 / 1e9,
                        "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},
