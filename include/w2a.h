@@ -174,6 +174,30 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
  * (t == 0 for every env, else W2A_ST_STEP_AFTER_DONE is raised). Used after w2a_sort_episodes. */
 int w2a_observe(w2a_env *env, float *obs, void *stream);
 
+/* On-device policy rollout (replaces a Python loop of `action = policy(obs); env.step(action)`
+ * such as env.py:265-277): every env runs up to n_steps days, or to the end of its episode, inside one launch
+ * with its coefficient rows held in registers. The policy sees what the reference's agent would see before
+ * acting on day t: the lagging observation (row of day t-1), the remaining budget and the day. */
+enum { W2A_POLICY_NEVER = 0, W2A_POLICY_ALWAYS = 1, W2A_POLICY_BERNOULLI = 2, W2A_POLICY_THRESHOLD = 3,
+       W2A_POLICY_TABLE = 4 };
+typedef struct w2a_policy {
+  int32_t kind;
+  float p;                /* BERNOULLI: P(alert); drawn from the counter RNG keyed (seed, env id, episode, day) */
+  int32_t obs_col;        /* THRESHOLD: observation column (reference order) of a table-sourced feature ...      */
+  float threshold;        /* ... alert iff obs[obs_col] > threshold                                              */
+  int32_t obs_lag;        /* THRESHOLD: 1 = the agent sees yesterday's row (faithful, Q6); 0 = today's row        */
+  int32_t require_budget; /* 1: never attempt an alert with remaining_budget <= 0                                */
+  const uint8_t *table;   /* TABLE: device uint8 [T][table_R], action = table[day][min(remaining_budget, R-1)]   */
+  int32_t table_R;
+  uint64_t seed;
+} w2a_policy;
+/* Outputs (device, nullable): ret_out f32 [n] rewards summed over the days run by this call, alerts_out i32 [n]
+ * alerts issued, attempts_over_budget i32 [n] alerts attempted at budget (silently dropped, Q5), alert_mask
+ * u32 [n][mask_words] bit d = alert issued on day d, last_return f32 [n] episode return of envs that finished. */
+int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
+                int32_t *attempts_over_budget, uint32_t *alert_mask, int32_t mask_words, float *last_return,
+                void *stream);
+
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
 

@@ -138,9 +138,12 @@ class RefData:
         self.columns = list(exo_cols) + list(endo_cols)
         endo = np.stack([np.asarray(getattr(d, c), np.float64) for c in endo_cols], axis=-1)
         full = np.concatenate([d.exo.astype(np.float64), endo], axis=-1)
+        ragged = d.meta.get("n_days_per_episode")  # optional [S_w, Y] episode lengths, 0 = pair absent
         for ci, f in enumerate(d.fips_weather):
             for yi, y in enumerate(d.years):
-                self.episodes[(f, int(y))] = full[ci, yi]
+                nd = full.shape[2] if ragged is None else int(ragged[ci][yi])
+                if nd > 0:
+                    self.episodes[(f, int(y))] = full[ci, yi, :nd]
         self.valid_years = [int(y) for y in d.years]
         self.fips_list = list(d.fips_list)
         self.conf_fips, self.conf_zone = list(d.confounder_fips), list(d.confounder_zone)
@@ -395,6 +398,52 @@ class VectorOracle:
         return self.obs.copy(), reward, done, actual
 
 
+def oracle_rollout(V: "VectorOracle", policy: dict, n_steps: int, seed_stream=None):
+    """Policy loop `a = policy(obs); step(a)` on the vector oracle (the pattern of env.py:265-277), for
+    checking w2a_rollout. policy: dict(kind, p, col, threshold, lag, require_budget, table); `seed_stream(i, t)`
+    returns the uniform [0,1) draw of env i on day t for the Bernoulli policy. Returns per-env
+    (ret, alerts, attempts_over_budget, alert_days bool [n, T])."""
+    n = len(V.t)
+    T = V.X.shape[2]
+    ret = np.zeros(n)
+    alerts = np.zeros(n, np.int64)
+    over = np.zeros(n, np.int64)
+    days = np.zeros((n, T), bool)
+    finished = (V.t >= V.n_days - 1) & getattr(V, "_finished", np.zeros(n, bool))
+    V._finished = finished.copy()
+    for _ in range(n_steps):
+        live = ~V._finished
+        if not live.any():
+            break
+        rem = V.budget - V.used
+        kind = policy["kind"]
+        if kind == "never":
+            act = np.zeros(n, np.int64)
+        elif kind == "always":
+            act = np.ones(n, np.int64)
+        elif kind == "bernoulli":
+            u = np.asarray([seed_stream(i, int(V.t[i])) for i in range(n)])
+            act = (u.astype(np.float32) < np.float32(policy["p"])).astype(np.int64)
+        elif kind == "threshold":
+            tt = np.where((V.t > 0) & (policy.get("lag", 1) == 1), V.t - 1, V.t)
+            feat = V.X[V.county_w, V.year_i, tt, policy["col"]]
+            act = (feat.astype(np.float32) > np.float32(policy["threshold"])).astype(np.int64)
+        else:
+            R = policy["table"].shape[1]
+            act = policy["table"][V.t, np.clip(rem, 0, R - 1)].astype(np.int64)
+        if policy.get("require_budget"):
+            act = np.where(rem <= 0, 0, act)
+        tday = V.t.copy()
+        atb = V.used == V.budget
+        _, r, done, actual = V.step(act)
+        ret += np.where(live, r, 0.0)
+        alerts += np.where(live, actual, 0)
+        over += np.where(live & (act == 1) & atb, 1, 0)
+        days[np.arange(n)[live & (actual == 1)], tday[live & (actual == 1)]] = True
+        V._finished = V._finished | (live & done)
+    return ret, alerts, over, days
+
+
 # --------------------------------------------------------------------------------------
 # Restatement of the build's counter-based device RNG (no reference counterpart)
 # --------------------------------------------------------------------------------------
@@ -421,6 +470,13 @@ def devrng_bounded(stream: int, slot: int, n: int) -> int:
     """uniform in [0, n): high 32 bits of the slot's word, multiply-shift."""
     u = _mix64(stream + (slot + 1) * 0x9E3779B97F4A7C15) >> 32
     return (u * n) >> 32
+
+
+def devrng_policy_uniform(policy_seed: int, env_gid: int, episode_no: int, day: int) -> float:
+    """The Bernoulli policy's uniform draw of k_rollout for (env, episode, day), as float32 in [0, 1)."""
+    st = devrng_stream(policy_seed ^ 0xA5A5A5A55A5A5A5A, env_gid, episode_no)
+    u = _mix64(st + (day + 1) * 0x9E3779B97F4A7C15) >> 32
+    return float(np.float32(u) * np.float32(2.3283064365386963e-10))
 
 
 def devrng_reset_tuple(seed, env_gid, episode_no, S, n_years, n_samples, fips_to_weather, sim_ptr, sim_cnt,

@@ -422,3 +422,144 @@ def test_sorted_episode_order_is_a_relabelling(dev, path):
     assert srt.check_status() == 0
     iid.close()
     srt.close()
+
+
+def test_ragged_episode_lengths_and_missing_pairs(dev):
+    """Episodes of different length finish on different steps (stale terminal obs, Q6), a missing
+    (county, year) pair is a KeyError at reset like the reference's .loc (env.py:127), and device-RNG mode
+    refuses tables with holes."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=12, years=[2006, 2007, 2008], n_samples=5, seed=13)
+    rng = np.random.default_rng(1)
+    nd = rng.integers(100, 154, size=(12, 3))
+    nd[0, 0] = 153
+    sd.meta["n_days_per_episode"] = nd
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    assert np.array_equal(V.n_days_tab.reshape(-1), ct.n_days)
+    n = 777
+    county = rng.integers(0, ct.S, n)
+    ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
+              sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 9, n))
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    assert not env._lockstep
+    obs, _ = env.reset(options={"episodes": ep})
+    obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
+    finished = np.zeros(n, bool)
+    for t in range(153):
+        a = (rng.random(n) < 0.3).astype(np.int32)
+        a[finished] = 0
+        obs, r, done, _, _ = env.step(torch.as_tensor(a, device=dev))
+        obs_o, r_o, done_o, _ = V.step(a)
+        live = ~finished
+        np.testing.assert_array_equal(done.cpu().numpy()[live], done_o[live])
+        assert np.abs(r.cpu().numpy() - r_o)[live].max() <= REWARD_TOL
+        np.testing.assert_array_equal(obs.cpu().numpy()[live], obs_o.astype(np.float32)[live])
+        finished |= done_o
+    assert finished.all()
+    np.testing.assert_array_equal(env.state()["t"].cpu().numpy(), V.n_days - 1)
+    env.close()
+    # holes
+    nd2 = nd.copy()
+    nd2[3, 1] = 0
+    sd.meta["n_days_per_episode"] = nd2
+    ct2 = tables.compile_from_synth(sd)
+    e2 = HeatAlertVecEnv(4, tables=ct2, device=dev, seed_mode="numpy_parity", autoreset="disabled")
+    with pytest.raises(KeyError):
+        e2.reset(options={"episodes": dict(county_w=3, year_i=1, coef_col=0, sample=0)})
+    seeds = [s for s in range(200) if int(np.random.default_rng(s).choice(ct2.years)) == ct2.years[1]][:4]
+    with pytest.raises(KeyError):
+        e2.reset(seed=seeds, options={"location": ct2.fips_weather[3]})
+    e2.close()
+    e3 = HeatAlertVecEnv(4, tables=ct2, device=dev)
+    with pytest.raises(KeyError):
+        e3.reset(seed=0)
+    e3.close()
+
+
+def _oracle_for_env(env, V):
+    st = {k: v.cpu().numpy() for k, v in env.state().items()}
+    V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    V._finished = np.zeros(len(st["t"]), bool)
+    return st
+
+
+@pytest.mark.parametrize("kind", ["never", "always", "bernoulli", "threshold", "threshold_lag0", "table"])
+def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
+    """w2a_rollout (whole episode in one launch, coefficients in registers) against the Python loop
+    `a = policy(obs); env.step(a)` on the oracle: alerts, over-budget attempts and alert days exact,
+    returns to f32 accumulation accuracy; then mixing rollout() and step() on one env."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=30, years=[2006, 2007], n_samples=6, seed=17, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n, gid0 = 333, 1000
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", env_gid0=gid0, similar_climate_counties=True)
+    env.reset(seed=21, options={"budget": 7})
+    st = _oracle_for_env(env, V)
+    rng = np.random.default_rng(0)
+    table = (rng.random((ct.T, 5)) < 0.3).astype(np.uint8)
+    col = ct.columns.index("heat_qi")
+    pol = {"never": dict(kind="never"), "always": dict(kind="always"),
+           "bernoulli": dict(kind="bernoulli", p=0.15, seed=99),
+           "threshold": dict(kind="threshold", feature="heat_qi", threshold=0.8, require_budget=True),
+           "threshold_lag0": dict(kind="threshold", feature="heat_qi", threshold=0.7, lag=0),
+           "table": dict(kind="table", table=table)}[kind]
+    opol = dict(pol, col=col)
+    if kind == "bernoulli":
+        def draw(i, t):
+            return O.devrng_policy_uniform(99, gid0 + i, int(st["episode_no"][i]), t)
+    else:
+        draw = None
+    # --- first 40 days by rollout
+    out = env.rollout(pol, n_steps=40, alert_mask=True)
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, opol, 40, draw)
+    np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
+    np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    assert not out["done"].any()
+    # --- 10 days by step() with explicit actions, state stays consistent
+    for _ in range(10):
+        a = (rng.random(n) < 0.2).astype(np.int32)
+        _, r, _, _, _ = env.step(torch.as_tensor(a, device=dev))
+        _, r_o, _, _ = V.step(a)
+        assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+    # --- the rest of the episode by rollout
+    out = env.rollout(pol, alert_mask=True)
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, opol, ct.T, draw)
+    np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
+    np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    assert out["done"].all()
+    s2 = {k: v.cpu().numpy() for k, v in env.state().items()}
+    np.testing.assert_array_equal(s2["used"], V.used)
+    np.testing.assert_array_equal(s2["streak"], V.streak)
+    np.testing.assert_array_equal(s2["t"], V.t)
+    stats = HeatAlertVecEnv.episode_stats(out)
+    assert abs(stats["mean_alerts"] - al_o.mean()) < 1e-9
+    np.testing.assert_array_equal(stats["alert_day_hist"].numpy(), days_o.sum(0))
+    assert env.check_status() == 0
+    env.close()
+
+
+def test_rollout_evaluates_consecutive_episodes_in_lockstep(dev):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=4)
+    ct = tables.compile_from_synth(sd)
+    env = HeatAlertVecEnv(4096, tables=ct, device=dev)
+    env.reset(seed=1)
+    rets = []
+    for ep in range(3):
+        assert (env.state()["episode_no"] == ep).all()
+        out = env.rollout(dict(kind="threshold", feature="heat_qi", threshold=0.85, require_budget=True))
+        assert out["done"].all()
+        np.testing.assert_allclose(out["final_return"].cpu().numpy(), out["return"].cpu().numpy(), rtol=1e-6)
+        rets.append(float(out["return"].mean()))
+    never = env.rollout(dict(kind="never"))
+    assert float(never["alerts"].sum()) == 0 and len(set(rets)) == 3
+    env.close()

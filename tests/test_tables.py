@@ -97,3 +97,44 @@ def test_full_size_similar_anchor():
     cnt, ptr, idx = tables._similar_csr(full, full, [zones[f] for f in full])
     assert full.index("06037") == 84 and cnt[84] == 111
     assert synth.load_fips_list("nn_full_medicare_all").index("06037") == 82
+
+
+def test_ragged_real_artefacts(tmp_path, mini_root):
+    """Real-artefact shapes the reference would meet: episodes of different length, a
+    (county, year) pair missing altogether, rows in shuffled file order, years restricted by the ctor."""
+    import shutil
+
+    import pandas as pd
+
+    root = tmp_path / "ragged"
+    shutil.copytree(mini_root, root)
+    ddir = root / "data" / "65k"
+    exo = pd.read_parquet(ddir / "exogenous_states.parquet")
+    endo = pd.read_parquet(ddir / "endogenous_states_actions.parquet")
+    f0, f1, f2 = sorted(exo.fips.unique())[:3]
+    drop = ((exo.fips == f0) & (exo.date >= "2006-09-11")) | ((exo.fips == f1) & (exo.date.str[:4] == "2007")) | \
+           ((exo.fips == f2) & (exo.date.str[:7] == "2008-05"))
+    exo = exo[~drop].sample(frac=1.0, random_state=1)  # shuffled rows: episode order = file order within a pair
+    exo.to_parquet(ddir / "exogenous_states.parquet")
+    ct = tables.compile_from_files(str(root), "linear")
+    rd = O.RefData.from_files(str(root), "linear")
+    assert ct.years == rd.valid_years and ct.fips_weather == [f for f in pd.unique(exo.fips)]
+    lens = set()
+    for ci, f in enumerate(ct.fips_weather):
+        for yi, y in enumerate(ct.years):
+            r = ci * ct.Y + yi
+            ep = rd.episodes.get((f, y))
+            if ep is None:
+                assert ct.n_days[r] == 0
+                continue
+            assert ct.n_days[r] == ep.shape[0]
+            lens.add(int(ct.n_days[r]))
+            assert ct.B0[r] == ep[0, rd.columns.index("remaining_budget")]
+            np.testing.assert_array_equal(ct.X[: ep.shape[0], r, ct.slot_of["dos"]],
+                                          ep[:, rd.columns.index("dos")].astype(np.float32))
+            assert (ct.X[ep.shape[0]:, r] == 0).all()
+    r1 = ct.fips_weather.index(f1) * ct.Y + ct.years.index(2007)
+    assert ct.n_days[r1] == 0 and lens == {153, 133, 122}
+    # years=[...] restricts valid_years like the ctor argument (env.py:32,104)
+    ct2 = tables.compile_from_files(str(root), "linear", years=[2008, 2006])
+    assert ct2.years == [2008, 2006] and ct2.Y == 2

@@ -21,8 +21,15 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
-    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe",
+    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout",
 ]
+POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
+
+
+class Policy(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p", C.c_float), ("obs_col", C.c_int32), ("threshold", C.c_float),
+                ("obs_lag", C.c_int32), ("require_budget", C.c_int32), ("table", C.c_void_p),
+                ("table_R", C.c_int32), ("seed", C.c_uint64)]
 
 
 class Tables(C.Structure):
@@ -104,6 +111,8 @@ def load(build_if_missing: bool = True):
     lib.w2a_sort_episodes.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
     lib.w2a_observe.restype = C.c_int
     lib.w2a_observe.argtypes = [vp, vp, vp]
+    lib.w2a_rollout.restype = C.c_int
+    lib.w2a_rollout.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, i32, vp, vp]
     if lib.w2a_abi_version() != ABI_VERSION:
         raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib

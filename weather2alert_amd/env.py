@@ -441,6 +441,98 @@ class HeatAlertVecEnv:
                                          device=self.device), self._obs_ptr)
         return self._obs, self._reward, done, self._truncated, _LazyInfo(self)
 
+    # ------------------------------------------------------------------ rollout
+    def rollout(self, policy: dict, n_steps: int | None = None, alert_mask: bool = False) -> dict:
+        """Run a built-in policy inside the kernel for ``n_steps`` days (default: to the end of the episode)
+        without returning to Python between days (replaces loops like env.py:265-277).
+
+        policy: {"kind": "never" | "always"} |
+                {"kind": "bernoulli", "p": 0.1, "seed": 0} |
+                {"kind": "threshold", "feature": "heat_qi", "threshold": 0.9, "lag": 1} |
+                {"kind": "table", "table": uint8 [T, R]}   (action = table[day][min(remaining_budget, R-1)])
+                plus optional "require_budget": True (never attempt an alert with no budget left).
+        The threshold policy sees the lagging observation the reference's agent would see (Q6; lag=0 reads
+        today's row instead). Returns device tensors: "return" (rewards summed over the days run), "alerts",
+        "attempts_over_budget", "final_return" (episode return of envs that finished), "done", and with
+        alert_mask=True "alert_days" bool [N, T]. In lock-step same_step-autoreset mode a finished batch is
+        reset, so consecutive calls evaluate consecutive episodes."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before rollout()")
+        ct = self.ct
+        kind = policy.get("kind")
+        if kind not in _ffi.POLICY_KINDS:
+            raise ValueError(f"policy kind {kind!r}")
+        p = _ffi.Policy()
+        p.kind = _ffi.POLICY_KINDS[kind]
+        p.p = float(policy.get("p", 0.0))
+        p.require_budget = int(bool(policy.get("require_budget", False)))
+        p.seed = int(policy.get("seed", 0)) & (2**64 - 1)
+        p.obs_lag = int(policy.get("lag", 1))
+        keep = None
+        if kind == "threshold":
+            feat = policy["feature"]
+            if feat not in ct.feature_names:
+                raise KeyError(feat)
+            p.obs_col, p.threshold = ct.feature_names.index(feat), float(policy["threshold"])
+        if kind == "table":
+            keep = torch.as_tensor(policy["table"], device=self.device).to(torch.uint8).contiguous()
+            if keep.dim() != 2 or keep.shape[0] < ct.T:
+                raise ValueError(f"policy table must be [T >= {ct.T}, R]")
+            p.table, p.table_R = keep.data_ptr(), int(keep.shape[1])
+        n, dev = self.num_envs, self.device
+        steps = int(n_steps) if n_steps is not None else ct.T
+        out = {"return": torch.empty(n, dtype=torch.float32, device=dev),
+               "alerts": torch.empty(n, dtype=torch.int32, device=dev),
+               "attempts_over_budget": torch.empty(n, dtype=torch.int32, device=dev)}
+        words = (ct.T + 31) // 32
+        mask = torch.empty((n, words), dtype=torch.int32, device=dev) if alert_mask else None
+        with torch.cuda.device(dev):
+            _ffi.check(self._lib.w2a_rollout(self._h, C.byref(p), steps, out["return"].data_ptr(),
+                                             out["alerts"].data_ptr(), out["attempts_over_budget"].data_ptr(),
+                                             None if mask is None else mask.data_ptr(), words, self._fr_ptr,
+                                             self._stream()), "w2a_rollout")
+        self._keep_pol = keep
+        st = self.state()
+        out["done"] = st["t"] + 1 >= st["n_days"]
+        out["final_return"] = self._final_return.clone()
+        if mask is not None:
+            bits = torch.arange(32, device=dev, dtype=torch.int32)
+            out["alert_days"] = (((mask.unsqueeze(-1) >> bits) & 1).reshape(n, words * 32)[:, : ct.T]).bool()
+        if self._host_auto:
+            self._steps_in_episode = min(self._steps_in_episode + steps, self._episode_len)
+            if self._steps_in_episode >= self._episode_len:
+                self._launch_device_reset(None, self._obs_ptr)
+        return out
+
+    @staticmethod
+    def episode_stats(out: dict) -> dict:
+        """Batch statistics of finished rollouts -- what the reference's SB3 callbacks try to log
+        (callbacks.py:18-87): mean return, alerts per episode, how often alerts were attempted over budget,
+        the histogram of alert days, alert-streak mean/std, and the day by which 50/80/100 % of an episode's
+        alerts were issued. Needs rollout(..., alert_mask=True) for the day-resolved entries."""
+        s = {"mean_return": float(out["return"].double().mean()),
+             "mean_alerts": float(out["alerts"].double().mean()),
+             "over_budget_freq": float((out["attempts_over_budget"] > 0).double().mean()),
+             "mean_attempts_over_budget": float(out["attempts_over_budget"].double().mean())}
+        if "alert_days" in out:
+            a = out["alert_days"]
+            s["alert_day_hist"] = a.sum(0).cpu()
+            af = a.to(torch.int32)
+            starts = af[:, :1].clone()
+            starts = torch.cat([starts, (af[:, 1:] == 1) & (af[:, :-1] == 0)], 1).to(torch.int32)
+            n_streaks = starts.sum(1)
+            has = n_streaks > 0
+            mean_len = af.sum(1)[has].double() / n_streaks[has].double()
+            s["streak_mean"] = float(mean_len.mean()) if has.any() else 0.0
+            s["streak_std"] = float(mean_len.std()) if has.sum() > 1 else 0.0
+            cum = af.cumsum(1)
+            tot = cum[:, -1:]
+            for q in (50, 80, 100):
+                need = torch.ceil(tot.double() * q / 100.0)
+                day = ((cum.double() >= need) & (tot > 0)).to(torch.int32).argmax(1)
+                s[f"day_{q}pct_alerts"] = float(day[has].double().mean()) if has.any() else float("nan")
+        return s
+
     def _coerce_actions(self, actions):
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions), device=self.device)

@@ -300,7 +300,12 @@ def compile_from_synth(d, sorted_keys: bool = True) -> CompiledTables:
     Xv[..., SLOT_BIAS] = 1.0
     Xv[..., SLOT_GATE] = Xv[..., slot_of["heat_qi"]]
     n_days = np.full(S_w * Y, T, np.int64)
-    B0 = d.remaining_budget[:, :, 0].reshape(-1).astype(np.int64)
+    ragged = d.meta.get("n_days_per_episode")  # optional [S_w, Y] episode lengths (0 = pair absent)
+    if ragged is not None:
+        n_days = np.asarray(ragged, np.int64).reshape(-1)
+        dead = np.arange(T)[:, None] >= n_days[None, :]
+        X[dead] = 0.0
+    B0 = np.where(n_days > 0, d.remaining_budget[:, :, 0].reshape(-1), 0).astype(np.int64)
     return _finish(columns, d.fips_weather, d.years, T, X, n_days, B0, post, d.fips_list, d.confounder_fips,
                    d.confounder_zone, d.meta.get("sig_categories", []), True, slot_of, obs_slot)
 
