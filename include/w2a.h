@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 2
+#define W2A_ABI_VERSION 3
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 #define W2A_LANES_PER_ENV 8
 
@@ -95,6 +95,10 @@ typedef struct w2a_tables {
   const int32_t *weather_to_fips; /* [S_w] county row of X -> its weight column, -1 = none                     */
   const void *L;                  /* [T][S_w*Y][n_samples] double2 {baseline, gated effectiveness} exogenous logits */
   const void *Wendo;              /* [S*n_samples][2][4] f32: coefficients of the 4 run-time slots per head    */
+  /* optional, for the corrected-semantics flags (w2a_set_semantics): */
+  const int32_t *sim_ptr;         /* [S+1] CSR of similar(county) ∩ fips_list, confounders order (W2A_FIX_AUGMENT)     */
+  const int32_t *sim_idx;         /* weight-column index of each similar county                                       */
+  int32_t slot_alerts_2wks;       /* slot of the historical 'alerts_2wks' column, -1 = absent (W2A_FIX_ALERTS_2WKS)    */
 } w2a_tables;
 
 typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */
@@ -173,6 +177,22 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
 /* First observation (env.py:181) of every env from its packed state; valid right after a reset
  * (t == 0 for every env, else W2A_ST_STEP_AFTER_DONE is raised). Used after w2a_sort_episodes. */
 int w2a_observe(w2a_env *env, float *obs, void *stream);
+
+/* Opt-in corrections of reference quirks. Default 0 = faithful to env.py, which is
+ * what every parity claim refers to; each bit is independent:
+ *   ALERTS_2WKS (Q1) the agent's 14-day alert count replaces the historical 'alerts_2wks' column (env.py:191
+ *                    writes it to a new key instead), so it reaches the reward through that coefficient
+ *   LAG         (Q3) alert_lag1 is yesterday's actual action (env.py:190 reads the buffer after today's append)
+ *   PENALTY     (Q5) an alert attempted at budget costs reward -1 (env.py:223-224 is dead code)
+ *   OBS         (Q6) step() returns the row of the next day with the updated state (env.py:257-259 returns the
+ *                    current day's row and a stale row on the terminal step)
+ *   AUGMENT     (Q8) similar_climate_counties uses the drawn county's weather and its true coefficient column
+ *                    (env.py:116-127 indexes the filtered list and keeps the requested county's weather);
+ *                    applies to device-RNG resets, host-tuple resets pass what they want
+ *   (Q9, per-episode budgets, is the `sticky = 0` argument of the reset entry points.) */
+enum { W2A_FIX_ALERTS_2WKS = 1, W2A_FIX_LAG = 2, W2A_FIX_PENALTY = 4, W2A_FIX_OBS = 8, W2A_FIX_AUGMENT = 16,
+       W2A_FIX_ALL = 31 };
+int w2a_set_semantics(w2a_env *env, uint32_t fixes);
 
 /* On-device policy rollout (replaces a Python loop of `action = policy(obs); env.step(action)`
  * such as env.py:265-277): every env runs up to n_steps days, or to the end of its episode, inside one launch

@@ -320,7 +320,11 @@ class VectorOracle:
     Episode tuple per env: county_w (row of X), year_i, coef_col, sample, budget, n_days.
     """
 
-    def __init__(self, d: RefData, fips_weather: list[str], years: list[int]):
+    def __init__(self, d: RefData, fips_weather: list[str], years: list[int], fixes=()):
+        # `fixes`: the build's opt-in corrections of reference quirks (include/w2a.h W2A_FIX_*: "alert_2wks",
+        # "lag", "penalty", "obs"); they have no reference counterpart -- the empty default is the pinned,
+        # reference-faithful behaviour
+        self.fixes = set(fixes)
         self.d = d
         self.fips_weather, self.years = list(fips_weather), [int(y) for y in years]
         T = max(v.shape[0] for v in d.episodes.values())
@@ -339,6 +343,7 @@ class VectorOracle:
         self.i_streak = d.columns.index("alert_streak")
         self.i_rem = d.columns.index("remaining_budget")
         self.i_hq = d.columns.index("heat_qi")
+        self.i_h2w = d.columns.index("alerts_2wks") if "alerts_2wks" in d.columns else -1
         self.C = C
 
     def default_budget(self, county_w, year_i):
@@ -361,12 +366,14 @@ class VectorOracle:
         self.obs = self._get_obs()
         return self.obs.copy()
 
-    def _get_obs(self):
+    def _get_obs(self, lag_src=None):
         n = len(self.t)
         row = np.empty((n, self.C + 1), np.float64)
         row[:, :-1] = self.X[self.county_w, self.year_i, self.t]
-        row[:, self.i_lag1] = np.where(self.t > 0, self.last_actual, 0)
+        row[:, self.i_lag1] = np.where(self.t > 0, self.last_actual if lag_src is None else lag_src, 0)
         row[:, -1] = self.hist.sum(axis=1)
+        if "alert_2wks" in self.fixes and self.i_h2w >= 0:
+            row[:, self.i_h2w] = row[:, -1]
         row[:, self.i_streak] = self.streak
         row[:, self.i_rem] = self.budget - self.used
         return row
@@ -375,10 +382,11 @@ class VectorOracle:
         action = np.asarray(action, np.int64)
         self.at_budget = self.used == self.budget
         actual = np.where((action == 1) & self.at_budget, 0, action)
+        yesterday = self.last_actual
         self.hist = np.concatenate([self.hist[:, 1:], actual[:, None]], axis=1)
         self.last_actual = actual
         self.used = self.used + actual
-        row = self._get_obs()
+        row = self._get_obs(yesterday if "lag" in self.fixes else None)
         zb = np.zeros(len(action), np.float64)
         for j, c in enumerate(self.bcols):
             x = 1.0 if c < 0 else row[:, c]
@@ -390,11 +398,18 @@ class VectorOracle:
         baseline = _expit(zb)
         eff = _expit(ze) * (row[:, self.i_hq] > 0.5)
         reward = -1000 / 152 * baseline * (1 - eff * actual)
+        if "penalty" in self.fixes:
+            reward = np.where((action == 1) & self.at_budget, -1.0, reward)
         done = self.t >= self.n_days - 1
         nd = ~done
-        self.obs[nd] = row[nd]  # terminal step returns the stale observation (Q6)
+        if "obs" not in self.fixes:
+            self.obs[nd] = row[nd]  # terminal step returns the stale observation (Q6)
         self.t = np.where(nd, self.t + 1, self.t)
         self.streak = np.where(nd, np.where(actual == 1, self.streak + 1, 0), self.streak)
+        if "obs" in self.fixes:  # corrected: the next day's row with the advanced state; last row when done
+            nxt = self._get_obs()
+            self.obs[nd] = nxt[nd]
+            self.obs[done] = row[done]
         return self.obs.copy(), reward, done, actual
 
 

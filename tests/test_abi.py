@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 2
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 3
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
@@ -51,8 +51,8 @@ def test_host_only_entry_points(lib):
 
 
 def test_ffi_struct_layout_matches_header():
-    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 3 pointers, naturally aligned
-    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 3 * 8
+    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 5 pointers + 1 int32 (+4 pad), naturally aligned
+    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 5 * 8 + 8
     assert C.sizeof(_ffi.StateView) == 15 * 8
 
 

@@ -563,3 +563,73 @@ def test_rollout_evaluates_consecutive_episodes_in_lockstep(dev):
     never = env.rollout(dict(kind="never"))
     assert float(never["alerts"].sum()) == 0 and len(set(rets)) == 3
     env.close()
+
+
+@pytest.mark.parametrize("fixes", [("alert_2wks",), ("lag",), ("penalty",), ("obs",),
+                                   ("alert_2wks", "lag", "penalty", "obs")])
+def test_corrected_semantics_flags(dev, fixes):
+    """faithful=False flags: each correction alone and all together against the
+    oracle's statement of the same correction, and each one really changes the trajectory."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=6, seed=31)
+    ct = tables.compile_from_synth(sd)
+    rd = O.RefData.from_synth(sd)
+    V = O.VectorOracle(rd, sd.fips_weather, sd.years, fixes=fixes)
+    n = 2000
+    rng = np.random.default_rng(7)
+    county = rng.integers(0, ct.S, n)
+    ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
+              sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 6, n))
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", fixes=fixes)
+    ref = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    obs, _ = env.reset(options={"episodes": ep})
+    ref.reset(options={"episodes": ep})
+    obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
+    np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+    differs = False
+    for t in range(153):
+        a = (rng.random(n) < 0.3).astype(np.int32)
+        at = torch.as_tensor(a, device=dev)
+        obs, r, done, _, _ = env.step(at)
+        obs_f, r_f, _, _, _ = ref.step(at)
+        obs_o, r_o, done_o, _ = V.step(a)
+        assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+        np.testing.assert_array_equal(done.cpu().numpy(), done_o)
+        np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        differs |= (not torch.equal(obs, obs_f)) or (not torch.equal(r, r_f))
+    assert differs
+    if "penalty" in fixes:
+        pass
+    env.close()
+    ref.close()
+
+
+def test_corrected_augmentation_and_budget(dev):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=40, years=[2006, 2007, 2008], n_samples=10, seed=3, extra_confounder_fips=4)
+    ct = tables.compile_from_synth(sd)
+    n, gid0, seed = 600, 50, 11
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", env_gid0=gid0, similar_climate_counties=True,
+                          fixes={"augment", "budget"})
+    for episode in range(2):
+        env.reset(seed=seed, options={"sample_budget": True})
+        st = {k: v.cpu().numpy() for k, v in env.state().items()}
+        for i in range(0, n, 5):
+            s = O.devrng_stream(seed, gid0 + i, episode)
+            c0 = O.devrng_bounded(s, O.DRAW_COUNTY, ct.S)
+            li = O.devrng_bounded(s, O.DRAW_SIMILAR, int(ct.sim_cnt[c0]))
+            c1 = int(ct.similar_list(c0)[li])
+            assert st["coef_col"][i] == c1 and st["county_w"][i] == ct.fips_to_weather[c1]
+            b0 = int(ct.B0[st["county_w"][i] * ct.Y + st["year_i"][i]])
+            assert 0 <= st["budget"][i] <= b0  # sampled from the table budget every episode, never sticky
+        assert (st["sticky_budget"] == -1).all()
+    env.close()
+    with pytest.raises(ValueError):
+        HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", fixes={"alert_2wks"})
+    with pytest.raises(ValueError):
+        HeatAlertVecEnv(8, tables=ct, device=dev, fixes={"nonsense"})
+    e = HeatAlertVecEnv(8, tables=ct, device=dev, faithful=False)
+    assert e.fixes == {"alert_2wks", "lag", "penalty", "obs", "augment", "budget"}
+    e.close()

@@ -13,7 +13,8 @@ OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
+FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
 # every symbol include/w2a.h declares (checked by tests/test_abi.py against the header text)
@@ -21,7 +22,7 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
-    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout",
+    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_set_semantics",
 ]
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
 
@@ -39,6 +40,7 @@ class Tables(C.Structure):
         ("T", C.c_int32), ("S_w", C.c_int32), ("Y", C.c_int32), ("S", C.c_int32), ("n_samples", C.c_int32),
         ("n_obs", C.c_int32), ("obs_slot", C.c_int32 * ROW_FLOATS), ("slot_heat_qi", C.c_int32),
         ("weather_to_fips", C.c_void_p), ("L", C.c_void_p), ("Wendo", C.c_void_p),
+        ("sim_ptr", C.c_void_p), ("sim_idx", C.c_void_p), ("slot_alerts_2wks", C.c_int32),
     ]
 
 
@@ -111,6 +113,8 @@ def load(build_if_missing: bool = True):
     lib.w2a_sort_episodes.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
     lib.w2a_observe.restype = C.c_int
     lib.w2a_observe.argtypes = [vp, vp, vp]
+    lib.w2a_set_semantics.restype = C.c_int
+    lib.w2a_set_semantics.argtypes = [vp, C.c_uint32]
     lib.w2a_rollout.restype = C.c_int
     lib.w2a_rollout.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, i32, vp, vp]
     if lib.w2a_abi_version() != ABI_VERSION:

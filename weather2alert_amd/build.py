@@ -37,8 +37,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = f"{LIB}.{os.getpid()}.tmp"  # several ranks may build at once: private temp + atomic rename
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INC}", SRC,
-           "-o", LIB + ".tmp"]
+           "-o", tmp]
     cmd += os.environ.get("W2A_CXXFLAGS", "").split()  # e.g. -DLANES=8 for kernel-geometry A/B runs
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -48,7 +49,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     if verbose:
         print(r.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -124,8 +124,22 @@ struct DevTables {
   const int32_t *weather_to_fips;  // [S_w] inverse of fips_to_weather (-1: county has no coefficients); nullable
   const double2 *L;                // [T][S_w*Y][n_samples] {baseline, gated effectiveness} exogenous logits; nullable
   const float4 *Wendo;             // [S*n_samples][2] run-time-slot coefficients (slots 24..27) per head; nullable
+  const int32_t *sim_ptr;          // [S+1] CSR of similar(county) ∩ fips_list (only for W2A_FIX_AUGMENT); nullable
+  const int32_t *sim_idx;
   int32_t T, S_w, Y, S, n_samples, n_obs;
+  int32_t slot_hist2w;             // table slot of the historical 'alerts_2wks' column (-1: none)
+  uint32_t fixes;                  // W2A_FIX_* bits: opt-in corrections of reference quirks (0 = faithful)
 };
+// overwrite component `idx` (0 .. 4*QUADS-1) of a lane's row fragment without dynamic register indexing
+__device__ __forceinline__ void set_comp(float4 *x, int idx, float v) {
+#pragma unroll
+  for (int q = 0; q < QUADS; ++q) {
+    if (idx == 4 * q) x[q].x = v;
+    if (idx == 4 * q + 1) x[q].y = v;
+    if (idx == 4 * q + 2) x[q].z = v;
+    if (idx == 4 * q + 3) x[q].w = v;
+  }
+}
 #define SAMPLE_BITS 12
 #define PACK_W(coef_col, sample) (((uint32_t)(coef_col) << SAMPLE_BITS) | (uint32_t)(sample))
 #define W_COL(y) ((y) >> SAMPLE_BITS)
@@ -226,6 +240,11 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
     int32_t ns = tb.sim_cnt[county];
     if (ns <= 0) { bad = 1; ns = 1; }
     coef_col = rng_bounded(st, 1, (uint32_t)ns);  // position inside the filtered list
+    if ((tb.fixes & W2A_FIX_AUGMENT) && tb.sim_idx) {
+      // corrected augmentation: the drawn similar county supplies both the weather and the coefficients
+      county = (uint32_t)tb.sim_idx[tb.sim_ptr[county] + (int32_t)coef_col];
+      coef_col = county;
+    }
   }
   uint32_t year_i = rng_bounded(st, 2, (uint32_t)tb.Y);
   uint32_t sample = rng_bounded(st, 3, (uint32_t)tb.n_samples);
@@ -326,8 +345,9 @@ struct StepArgs {
 #endif                   // latency-bound and measured faster at full occupancy
 // The in-kernel autoreset variants carry the episode draw and would spill at 64 VGPRs (measured 1.4x slower),
 // so they keep the compiler's own allocation; lock-step batches use the plain variant + k_reset instead.
-template <bool AUTORESET, bool WRITE_OBS, bool TABLE>
-__global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
+// FIXES: compiled-in support for the W2A_FIX_* corrections; the faithful variants carry none of that code.
+template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
+__global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -375,11 +395,16 @@ __global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(c
     if (WRITE_OBS) so[q] = reinterpret_cast<const int4 *>(a.slot_obs)[l * QUADS + q];
   }
   // env.py:190-193 run-time fields (slots 24..27)
-  const float f_lag1 = (t > 0) ? (float)actual : 0.0f;   // alert_lag1: today's action for t>0 (Q3)
+  const uint32_t fx = FIXES ? a.tb.fixes : 0u;
+  // alert_lag1: today's action for t>0 (Q3); W2A_FIX_LAG: yesterday's
+  const float f_lag1 = (t > 0) ? (float)((fx & W2A_FIX_LAG) ? D0_LAST(hot.x) : actual) : 0.0f;
   const float f_streak = (float)streak;                  // streak before today's action (Q4)
   const float f_rem = (float)(budget - (int32_t)used2);  // remaining_budget
   const float f_a2w = (float)__popc(hist2);              // agent's 14-day count ('alert_2wks', Q1)
   if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(f_lag1, f_streak, f_rem, f_a2w);
+  // W2A_FIX_ALERTS_2WKS: the agent's count also replaces the historical 'alerts_2wks' column, so it feeds the reward
+  if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+    set_comp(x, a.tb.slot_hist2w % (4 * QUADS), f_a2w);
   double zb, ze;
   if (TABLE) {
     // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
@@ -427,7 +452,8 @@ __global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(c
   const float base = sigmoid_f32((float)zb);
   const float eff = sigmoid_f32((float)ze);
   // env.py:221
-  const float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  if ((fx & W2A_FIX_PENALTY) && act == 1 && atb) r = -1.0f;  // env.py:223-224 made live (dead in the reference, Q5)
 
   const bool done = (t + 1 >= ndays);  // env.py:256
   const uint32_t t2 = done ? t : t + 1;
@@ -438,6 +464,18 @@ __global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(c
                           __float_as_uint(ret), (uint32_t)budget);
   uint4 cold2 = cold;
   bool write_row = !done;
+  if (WRITE_OBS && (fx & W2A_FIX_OBS)) {
+    // corrected observation (Q6): the row of the day the next action applies to, with the state as updated
+    // by today's action; on the terminal step the last row (not a stale copy)
+    write_row = true;
+    if (!done) {
+#pragma unroll
+      for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[(day_row + rows_per_day) * (ROWF / 4) + l * QUADS + q];
+      if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4((float)actual, (float)streak2, f_rem, f_a2w);
+      if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+        set_comp(x, a.tb.slot_hist2w % (4 * QUADS), f_a2w);
+    }
+  }
   if (AUTORESET) {
     if (done) {
       // same-step autoreset: draw the next episode, emit its first observation (env.py:162-181)
@@ -449,6 +487,8 @@ __global__ __launch_bounds__(BLOCK, AUTORESET ? 1 : W2A_MIN_WAVES) void k_step(c
 #pragma unroll
         for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[ep.ep_row * (ROWF / 4) + l * QUADS + q];
         if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+        if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+          set_comp(x, a.tb.slot_hist2w % (4 * QUADS), 0.0f);
       }
       write_row = true;
     }
@@ -542,6 +582,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     so[q] = reinterpret_cast<const int4 *>(a.slot_obs)[l * QUADS + q];
   }
   if (l == RT_QUAD / QUADS) x[RT_QUAD % QUADS] = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+  if ((a.tb.fixes & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+    set_comp(x, a.tb.slot_hist2w % (4 * QUADS), 0.0f);  // the agent's (empty) history replaces the column
   if (valid && sel && l == 0) {
     if (a.from_tuples != 2) {
       a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
@@ -776,9 +818,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
     const float today = (a.pol.kind == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    const uint32_t fx = a.tb.fixes;
+    const float f_a2w = (float)__popc(hist2);
     if (l == RT_QUAD / QUADS)
-      x[RT_QUAD % QUADS] = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak,
-                                       (float)(budget - (int32_t)used2), (float)__popc(hist2));
+      x[RT_QUAD % QUADS] = make_float4((t > 0) ? (float)((fx & W2A_FIX_LAG) ? last : actual) : 0.0f, (float)streak,
+                                       (float)(budget - (int32_t)used2), f_a2w);
+    if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+      set_comp(x, a.tb.slot_hist2w % (4 * QUADS), f_a2w);
     double zb = 0.0, ze = 0.0;
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
@@ -791,7 +837,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     if (l == GATE_QUAD / QUADS && !(x[GATE_QUAD % QUADS].z > 0.5f)) ze = -__builtin_inf();
     zb = group_sum(zb);
     ze = group_sum(ze);
-    const float r = -(1000.0f / 152.0f) * sigmoid_f32((float)zb) * (1.0f - sigmoid_f32((float)ze) * (float)actual);
+    float r = -(1000.0f / 152.0f) * sigmoid_f32((float)zb) * (1.0f - sigmoid_f32((float)ze) * (float)actual);
+    if ((fx & W2A_FIX_PENALTY) && act == 1 && atb_s) r = -1.0f;
     if (active) {
       const bool done = (t + 1 >= ndays);
       ret += r;
@@ -908,6 +955,10 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->tb.fips_to_weather = t->fips_to_weather;
   h->tb.sim_cnt = t->sim_cnt;
   h->tb.weather_to_fips = t->weather_to_fips;
+  h->tb.sim_ptr = t->sim_ptr;
+  h->tb.sim_idx = t->sim_idx;
+  h->tb.slot_hist2w = t->slot_alerts_2wks;
+  h->tb.fixes = 0;
   h->tb.L = reinterpret_cast<const double2 *>(t->L);
   h->tb.Wendo = reinterpret_cast<const float4 *>(t->Wendo);
   h->tb.T = t->T; h->tb.S_w = t->S_w; h->tb.Y = t->Y; h->tb.S = t->S; h->tb.n_samples = t->n_samples;
@@ -1007,7 +1058,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
-#define W2A_LAUNCH(AR, OB, TB) hipLaunchKernelGGL((k_step<AR, OB, TB>), grid, block, 0, s, a)
+#define W2A_LAUNCH(AR, OB, TB) \
+  do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, TB, true>), grid, block, 0, s, a); \
+       else hipLaunchKernelGGL((k_step<AR, OB, TB, false>), grid, block, 0, s, a); } while (0)
   const int variant = (autoreset ? 4 : 0) | (no_obs ? 0 : 2) | (table ? 1 : 0);
   switch (variant) {
     case 0: W2A_LAUNCH(false, false, false); break;
@@ -1107,6 +1160,20 @@ int w2a_observe(w2a_env *env, float *obs, void *stream) {
   memset(&a, 0, sizeof(a));
   a.obs = obs; a.from_tuples = 2;
   return launch_reset(env, a, stream);
+}
+
+int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_set_semantics: NULL handle");
+  if (fixes & ~(uint32_t)W2A_FIX_ALL) return fail(W2A_ERR_ARG, "w2a_set_semantics: unknown W2A_FIX_* bit");
+  if ((fixes & W2A_FIX_AUGMENT) && (!env->tb.sim_ptr || !env->tb.sim_idx))
+    return fail(W2A_ERR_ARG, "w2a_set_semantics: W2A_FIX_AUGMENT needs sim_ptr/sim_idx in the tables");
+  if ((fixes & W2A_FIX_ALERTS_2WKS) && env->tb.L)
+    return fail(W2A_ERR_ARG, "w2a_set_semantics: W2A_FIX_ALERTS_2WKS moves a coefficient out of the precomputed logit "
+                             "table; create the handle without L/Wendo (row-gather path)");
+  if ((fixes & W2A_FIX_ALERTS_2WKS) && env->tb.slot_hist2w >= W2A_ROW_FLOATS)
+    return fail(W2A_ERR_SCHEMA, "w2a_set_semantics: slot_alerts_2wks out of range");
+  env->tb.fixes = fixes;
+  return W2A_OK;
 }
 
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,

@@ -24,6 +24,7 @@ from .tables import CompiledTables, DeviceTables, compile_from_files
 _ACT_CODES = {torch.int32: _ffi.ACT_I32, torch.int64: _ffi.ACT_I64, torch.uint8: _ffi.ACT_U8,
               torch.bool: _ffi.ACT_U8}
 _BUDGET_MODES = {"less_than": _ffi.BUDGET_LESS_THAN, "centered": _ffi.BUDGET_CENTERED}
+_cur_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
 
 class HeatAlertVecEnv:
@@ -57,6 +58,12 @@ class HeatAlertVecEnv:
                          variant). False: each env restarts inside the step kernel whenever it finishes (needed
                          after partial resets). None (default): True when the tables allow it; falls back to
                          False by itself after a masked reset.
+    faithful / fixes     faithful=True (default) reproduces every reference quirk -- all parity
+                         claims refer to this mode. ``fixes`` opts into individual corrections (faithful=False =
+                         all of them): "alert_2wks" (Q1: the agent's 14-day count feeds the reward), "lag" (Q3:
+                         alert_lag1 is yesterday's action), "penalty" (Q5: -1 for an alert attempted at budget),
+                         "obs" (Q6: step() returns the next day's row), "augment" (Q8: the drawn similar county
+                         supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -82,6 +89,8 @@ class HeatAlertVecEnv:
         reward_path: Literal["gather", "table", "auto"] = "gather",
         episode_order: Literal["iid", "sorted"] = "iid",
         lockstep: bool | None = None,
+        faithful: bool = True,
+        fixes: set | list | None = None,
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -112,6 +121,12 @@ class HeatAlertVecEnv:
         if reward_path == "table" and self.similar_climate_counties:
             raise ValueError("reward_path='table' cannot serve similar_climate_counties=True (Q8 pairs a county's "
                              "weather with another county's coefficients); use 'gather'")
+        allf = set(_ffi.FIX_BITS) | {"budget"}
+        self.fixes = set(allf) if (not faithful and fixes is None) else set(fixes or ())
+        if self.fixes - allf:
+            raise ValueError(f"unknown fixes {sorted(self.fixes - allf)}; choose from {sorted(allf)}")
+        if "alert_2wks" in self.fixes and reward_path == "table":
+            raise ValueError("fixes={'alert_2wks'} moves a coefficient out of the logit table; use reward_path='gather'")
         self.reward_path = reward_path
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
@@ -146,6 +161,9 @@ class HeatAlertVecEnv:
             _ffi.check(self._lib.w2a_create(C.byref(self.dtables.struct), n, self.env_gid0, self._state.data_ptr(),
                                             nbytes, self._status.data_ptr(), C.byref(h)), "w2a_create")
         self._h = h
+        bits = sum(_ffi.FIX_BITS[k] for k in self.fixes if k in _ffi.FIX_BITS)
+        if bits:
+            _ffi.check(self._lib.w2a_set_semantics(h, bits), "w2a_set_semantics")
         # hot-path constants (step() is called millions of times: no per-call attribute chains)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._obs_ptr = self._obs.data_ptr() if self.write_obs else None
@@ -336,6 +354,9 @@ class HeatAlertVecEnv:
                     raise KeyError(location)  # confounders.loc[fips] (datautils.py:123)
                 li = int(rng.choice(range(ns)))  # env.py:117
                 self._info_location[i] = ct.fips_list[int(ct.similar_list(county)[li])]
+                if "augment" in self.fixes:  # corrected Q8: the drawn county supplies weather and coefficients
+                    county = li = int(ct.similar_list(county)[li])
+                    location = ct.fips_list[county]
             else:
                 li = county
                 self._info_location[i] = location
@@ -355,7 +376,7 @@ class HeatAlertVecEnv:
                     b = int(rng.integers(0, b + 1))
                 elif typ == "centered":
                     b = int(rng.integers(0.5 * b, 1.5 * b + 1))
-            self._sticky[i] = b
+            self._sticky[i] = self._ctor_budget if "budget" in self.fixes else b
             cw[i], yi[i], cc[i], sm[i], bd[i] = w, y_i, li, ci, b
         self._reset_tuples(dict(county_w=cw, year_i=yi, coef_col=cc, sample=sm, budget=bd), mask_t, obs_ptr)
 
@@ -381,7 +402,7 @@ class HeatAlertVecEnv:
             mode = _BUDGET_MODES[typ]
         if seed is None:
             seed = int(np.random.randint(0, 2**31 - 1))
-        return int(seed) & (2**64 - 1), loc_i, int(aug), -1 if bk is None else int(bk), mode, 1
+        return int(seed) & (2**64 - 1), loc_i, int(aug), -1 if bk is None else int(bk), mode, int("budget" not in self.fixes)
 
     def _reset_device(self, seed, options, mask_t, obs_ptr):
         ct = self.ct
@@ -424,6 +445,9 @@ class HeatAlertVecEnv:
         if (type(actions) is not torch.Tensor or actions.device != self.device or actions.dtype not in _ACT_CODES
                 or actions.numel() != self.num_envs or not actions.is_contiguous()):
             actions = self._coerce_actions(actions)
+        if _cur_device() != self._dev_index:  # kernels launch on the current device: it must be this env's
+            with torch.cuda.device(self.device):
+                return self.step(actions)
         rc = self._w2a_step(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype], self._obs_ptr, self._rew_ptr,
                             self._done_ptr, self._fr_ptr, self._step_flags, self._stream())
         if rc != 0:

@@ -344,6 +344,10 @@ class DeviceTables:
                 w2f[w] = i
         self.weather_to_fips = t(w2f)
         s.weather_to_fips = self.weather_to_fips.data_ptr()
+        self.sim_ptr = t(ct.sim_ptr.astype(np.int32))
+        self.sim_idx = t(ct.sim_idx.astype(np.int32) if len(ct.sim_idx) else np.zeros(1, np.int32))
+        s.sim_ptr, s.sim_idx = self.sim_ptr.data_ptr(), self.sim_idx.data_ptr()
+        s.slot_alerts_2wks = ct.slot_of.get("alerts_2wks", -1)
         s.L, s.Wendo = None, None
         self.L = self.Wendo = None
         self.struct = s
