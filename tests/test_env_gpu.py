@@ -633,3 +633,54 @@ def test_corrected_augmentation_and_budget(dev):
     e = HeatAlertVecEnv(8, tables=ct, device=dev, faithful=False)
     assert e.fixes == {"alert_2wks", "lag", "penalty", "obs", "augment", "budget"}
     e.close()
+
+
+def test_budget_invariants_at_scale(dev):
+    """Size-independent properties over a full-size batch (1 048 576 envs, BASELINE configs[2] shape):
+    sum(actual) <= budget, remaining_budget = budget - used, used/streak/t monotone rules, the 14-day window
+    count is the popcount of the history, rewards lie in [-1000/152, 0], finished envs report their return."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
+    ct = tables.compile_from_synth(sd)
+    n = 1 << 20
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, autoreset="disabled")
+    obs, _ = env.reset(seed=4, options={"sample_budget": True})
+    names = ct.feature_names
+    i_rem, i_a2w, i_streak, i_lag = (names.index(k) for k in ("remaining_budget", "alert_2wks", "alert_streak",
+                                                             "alert_lag1"))
+    st0 = env.state()
+    budget = st0["budget"].clone()
+    assert (budget >= 0).all() and (obs[:, i_rem] == budget).all()
+    g = torch.Generator(device=dev).manual_seed(0)
+    used_prev = torch.zeros(n, dtype=torch.int32, device=dev)
+    ret = torch.zeros(n, dtype=torch.float64, device=dev)
+    attempts = torch.zeros(n, dtype=torch.int32, device=dev)
+    for t in range(153):
+        a = (torch.rand(n, device=dev, generator=g) < 0.3).to(torch.uint8)
+        obs, r, done, _, _ = env.step(a)
+        attempts += a.int()
+        ret += r.double()
+        assert (r <= 0).all() and (r >= -1000.0 / 152.0 - 1e-5).all()
+        if t % 19 == 0 or t >= 151:
+            st = env.state()
+            used = st["used"]
+            assert (used <= budget).all() and (used >= used_prev).all() and (used - used_prev <= 19).all()
+            assert (used <= attempts).all()
+            assert (st["at_budget"].bool() == (used - st["last_actual"] == budget)).all()
+            pop = torch.zeros_like(used)
+            for b in range(14):
+                pop += (st["hist14"] >> b) & 1
+            if t < 152:
+                assert (st["t"] == t + 1).all() and not done.any()
+                assert (obs[:, i_rem] == (budget - used).float()).all()
+                assert (obs[:, i_a2w] == pop.float()).all()
+                assert (obs[:, i_lag] == (st["last_actual"].float() if t > 0 else 0)).all()
+            used_prev = used.clone()
+    assert done.all()
+    st = env.state()
+    assert (st["used"] == torch.minimum(attempts, budget)).all()  # every attempt within budget is granted (Q5)
+    np.testing.assert_allclose(st["episode_return"].cpu().numpy(), ret.cpu().numpy(), rtol=3e-5)
+    np.testing.assert_allclose(env._final_return.cpu().numpy(), ret.cpu().numpy(), rtol=3e-5)
+    assert env.check_status() == 0
+    env.close()
