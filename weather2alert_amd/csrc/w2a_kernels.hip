@@ -658,10 +658,19 @@ __global__ __launch_bounds__(BLOCK) void k_logit_table(const LogitArgs a) {
   __shared__ float sB[LT_K][LT_NT * 16];
   const int c = blockIdx.x;
   const int cc = a.tb.weather_to_fips[c];
-  if (cc < 0) return;  // uniform per workgroup: county without coefficients
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Y = a.tb.Y, M = a.tb.Y * a.tb.T, N2 = 2 * a.tb.n_samples;
   const int R = a.tb.S_w * a.tb.Y;
+  if (cc < 0) {
+    // uniform per workgroup: a county without coefficients is never gathered; define its rows as zero
+    // (the caller's buffer is not pre-cleared: a 2 GB memset in front of this kernel costs as much as it does)
+    for (int m = blockIdx.y; m < M; m += a.msplit) {
+      const int tz = m / Y, yz = m - tz * Y;
+      double *row = a.L + ((size_t)tz * R + (size_t)c * Y + yz) * (size_t)N2;
+      for (int n = tid; n < N2; n += BLOCK) row[n] = 0.0;
+    }
+    return;
+  }
   const int mtiles = (M + 15) >> 4;
   const float *Xf = reinterpret_cast<const float *>(a.tb.X);
   const float *Wf = reinterpret_cast<const float *>(a.tb.W);
@@ -677,14 +686,30 @@ __global__ __launch_bounds__(BLOCK) void k_logit_table(const LogitArgs a) {
     }
     __syncthreads();
     const int ntiles = min(LT_NT, (N2 - n0 + 15) >> 4);
-    for (int mt = blockIdx.y * (BLOCK / 64) + wave; mt < mtiles; mt += (BLOCK / 64) * a.msplit) {
-      // A fragments: row m = mt*16 + col (clamped), k = 4*ks + q
-      const int m = min(mt * 16 + col, M - 1);
+    // m-tiles of this wave, software-pipelined: the next tile's A fragments and gate values are requested
+    // BEFORE this tile's stores are issued. vmcnt retires in order and counts stores, so loads issued after
+    // ~26 KB of stores would wait for all of them to drain (measured: 2.8 TB/s of writes instead of ~5).
+    const int mstep = (BLOCK / 64) * a.msplit;
+    float a_nx[LT_K / 4], g_nx[4];
+    auto request = [&](int mt_) {
+      const int m = min(mt_ * 16 + col, M - 1);
       const int tA = m / Y, yA = m - tA * Y;
       const float *xr = Xf + ((size_t)tA * R + (size_t)c * Y + yA) * ROWF;
+#pragma unroll
+      for (int ks = 0; ks < LT_K / 4; ++ks) a_nx[ks] = xr[lt_slot(4 * ks + q)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mm = min(mt_ * 16 + q + 4 * j, M - 1);
+        const int tj = mm / Y, yj = mm - tj * Y;
+        g_nx[j] = Xf[((size_t)tj * R + (size_t)c * Y + yj) * ROWF + 30];
+      }
+    };
+    int mt = blockIdx.y * (BLOCK / 64) + wave;
+    if (mt < mtiles) request(mt);
+    for (; mt < mtiles; mt += mstep) {
       double af[LT_K / 4];
 #pragma unroll
-      for (int ks = 0; ks < LT_K / 4; ++ks) af[ks] = (double)xr[lt_slot(4 * ks + q)];
+      for (int ks = 0; ks < LT_K / 4; ++ks) af[ks] = (double)a_nx[ks];
       // this lane's 4 output rows: q + 4j
       size_t orow[4];
       bool ok[4], gate[4];
@@ -695,8 +720,9 @@ __global__ __launch_bounds__(BLOCK) void k_logit_table(const LogitArgs a) {
         const int mm = min(mj, M - 1);
         const int tj = mm / Y, yj = mm - tj * Y;
         orow[j] = (size_t)tj * R + (size_t)c * Y + yj;
-        gate[j] = Xf[orow[j] * ROWF + 30] > 0.5f;
+        gate[j] = g_nx[j] > 0.5f;
       }
+      if (mt + mstep < mtiles) request(mt + mstep);
       for (int nt = 0; nt < ntiles; ++nt) {
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -704,16 +730,27 @@ __global__ __launch_bounds__(BLOCK) void k_logit_table(const LogitArgs a) {
           const double b = (double)sB[4 * ks + q][nt * 16 + col];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b, acc, 0, 0, 0);
         }
+        // epilogue: lanes (2k, 2k+1) hold adjacent columns of the same 4 rows; swap halves over DPP so that
+        // each lane owns a 16-B {col 2k, col 2k+1} pair of two rows -> 2 x 16-B stores instead of 4 x 8-B
         const int n = n0 + nt * 16 + col;
-        if (n < N2) {
+        const bool odd = (lane & 1) != 0;
+        double v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (ok[j]) {
-              double v = acc[j];
-              if ((n & 1) && !gate[j]) v = -__builtin_inf();
-              a.L[orow[j] * (size_t)N2 + n] = v;
-            }
-          }
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[j];
+          if ((n & 1) && !gate[j]) v[j] = -__builtin_inf();  // odd column = effectiveness head: closed gate
+        }
+        const double r0 = dpp_f64<0xB1>(odd ? v[0] : v[1]);
+        const double r1 = dpp_f64<0xB1>(odd ? v[2] : v[3]);
+        const int na = n & ~1;  // first column of the pair
+        if (na < N2) {          // N2 is even, so the pair is in range together
+          // even lane stores rows j = 0, 2; odd lane rows j = 1, 3 (selects, no dynamic register indexing)
+          const double2 p0 = odd ? make_double2(r0, v[1]) : make_double2(v[0], r0);
+          const double2 p1 = odd ? make_double2(r1, v[3]) : make_double2(v[2], r1);
+          const size_t ra = odd ? orow[1] : orow[0], rb = odd ? orow[3] : orow[2];
+          const bool oka = odd ? ok[1] : ok[0], okb = odd ? ok[3] : ok[2];
+          if (oka) *reinterpret_cast<double2 *>(a.L + ra * (size_t)N2 + na) = p0;
+          if (okb) *reinterpret_cast<double2 *>(a.L + rb * (size_t)N2 + na) = p1;
         }
       }
     }
@@ -1108,8 +1145,6 @@ int w2a_build_logit_table(const w2a_tables *t, void *L, size_t L_bytes, void *We
   a.L = reinterpret_cast<double *>(L);
   a.msplit = 4;
   hipStream_t s = (hipStream_t)stream;
-  // rows of absent (county, year) pairs and of counties without coefficients are never gathered; zero them anyway
-  HIP_TRY(hipMemsetAsync(L, 0, w2a_logit_table_bytes(t), s));
   hipLaunchKernelGGL(k_logit_table, dim3((unsigned)t->S_w, (unsigned)a.msplit), dim3(BLOCK), 0, s, a);
   HIP_TRY(hipGetLastError());
   const int64_t rows = (int64_t)t->S * t->n_samples;
