@@ -64,6 +64,57 @@ def parse():
     return p.parse_args()
 
 
+def _cpu_worker(args):
+    """One host process of the multi-core CPU baseline: builds its own tables (spawned, no GPU), steps the
+    NumPy vector oracle on its share of the envs and returns (env_steps, seconds spent stepping)."""
+    wname, seed, n, steps, rank = args
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd import synth, tables
+
+    sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=seed, extra_confounder_fips=60)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    rng = np.random.default_rng(seed + 1 + rank)
+    county = rng.integers(0, ct.S, n)
+    cc = rng.integers(0, np.maximum(ct.sim_cnt[county], 1))
+    V.reset(ct.fips_to_weather[county].astype(np.int64), rng.integers(0, ct.Y, n), cc,
+            rng.integers(0, ct.n_samples, n), rng.integers(0, 12, n))
+    acts = (rng.random((steps, n)) < 0.1).astype(np.int64)
+    V.step(acts[0])
+    t0 = time.perf_counter()
+    for t in range(1, steps):
+        V.step(acts[t])
+    return n * (steps - 1), time.perf_counter() - t0
+
+
+def cpu_baseline_multicore(wname, seed, procs, timeout=180):
+    """`procs` independent host processes (plain subprocesses of this script: no fork of a GPU process, no
+    multiprocessing start-method pitfalls), each stepping its own share; aggregate = total / slowest."""
+    import subprocess
+
+    n, steps = 16384, 154
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                            json.dumps([wname, seed, n, steps, r])], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           env=env, text=True) for r in range(procs)]
+    res = []
+    deadline = time.time() + timeout
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:  # noqa: BLE001
+            p.kill()
+    if len(res) != procs:
+        raise RuntimeError(f"{procs - len(res)} of {procs} CPU workers failed or timed out")
+    total = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {"value": total / slowest, "cores": procs,
+            "sample": f"{procs} processes x {n} envs x {steps - 1} steps, slowest worker {slowest:.1f} s"}
+
+
 def cpu_baseline(sd, ct, seed=0):
     """NumPy oracle (float64, vectorised over envs) timed on the host: bounded sample of the
     same workload. Also times the scalar per-env restatement of the reference's step()."""
@@ -107,6 +158,9 @@ def cpu_baseline(sd, ct, seed=0):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        print(json.dumps(_cpu_worker(tuple(json.loads(sys.argv[2])))))
+        return
     args = parse()
     import numpy as np
     import torch
@@ -229,6 +283,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
+            procs = min(16, os.cpu_count() or 1)
+            try:
+                out["cpu_baseline"]["multi_core"] = cpu_baseline_multicore(wname, args.seed, procs)
+            except Exception as e:  # noqa: BLE001  (a reported extra, never fatal)
+                out["cpu_baseline"]["multi_core"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     env.close()
     wdist.barrier()
