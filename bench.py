@@ -274,7 +274,12 @@ def main():
                        "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"k_step<autoreset,obs={not args.no_obs},table={rpath == 'table'}>",
+                         "kernel": f"k_step<autoreset={env._dev_auto},obs={not args.no_obs},table={rpath == 'table'}>"
+                                   + ("" if env._dev_auto else " + k_reset once per episode"),
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                         "measured_traffic_gbs": None if traffic is None else traffic / per_launch_s / 1e9,
+                         "note": "achieved uses SURVEY 8d algorithmic bytes; it can exceed the HBM peak because "
+                                 "the day slice of X is served by L2 and W by the Infinity Cache",
                          "avg_launch_us": per_launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "timing": "HIP events on the launch stream around the timed steps / steps"},
