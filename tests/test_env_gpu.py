@@ -66,7 +66,6 @@ def test_dropin_env_reproduces_reference_goldens(mini, dev):
         assert info["remaining_budget"] == d["reset_remaining_budget"][i]
         assert info["feature_names"] == meta["feature_names"]
         np.testing.assert_array_equal(obs, d["obs0"][i].astype(np.float32))
-        # stepping one env at a time is slow (syncs): check a prefix, the end and the budget edge
         for t in range(153):
             obs, r, done, trunc, info = env.step(int(d["actions"][i, t]))
             assert abs(r - d["reward"][i, t]) <= REWARD_TOL
@@ -599,8 +598,6 @@ def test_corrected_semantics_flags(dev, fixes):
         np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
         differs |= (not torch.equal(obs, obs_f)) or (not torch.equal(r, r_f))
     assert differs
-    if "penalty" in fixes:
-        pass
     env.close()
     ref.close()
 

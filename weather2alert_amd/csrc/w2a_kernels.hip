@@ -1,23 +1,25 @@
 // w2a_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of the vectorised HeatAlertEnv.
 //
 // What is computed follows the reference src/weather2alert/env.py:
-//   reset  :133-184 (+ _get_episode :107-131)      -> reset_env() / k_reset_*
-//   _get_obs :186-195, _get_reward :197-226, step :238-262 -> k_step
+//   reset  :133-184 (+ _get_episode :107-131)      -> draw_episode() / k_reset
+//   _get_obs :186-195, _get_reward :197-226, step :238-262 -> k_step (and k_rollout: many days per launch)
 // How it is computed is MI355X-first:
-//   * an env is served by an 8-lane group of a 64-wide wavefront (8 envs per wave, 32 per
-//     256-thread workgroup); lane l owns floats 4l..4l+3 of the env's 128-byte feature row
-//     and of its two 128-byte coefficient rows, so every gather is three 16-B loads per
-//     lane that together cover whole 128-B lines;
+//   * an env is served by a 4-lane group of a 64-wide wavefront (16 envs per wave, 64 per
+//     256-thread workgroup); lane l owns floats 8l..8l+7 of the env's 128-byte feature row
+//     and of its two 128-byte coefficient rows, so every gather is 16-B loads that together
+//     cover whole 128-B lines (LANES = 8 / 2 were measured slower);
 //   * feature rows are stored day-major ([T][county*year][32]); all envs of a lock-step
 //     batch read the same ~1 MB day slice, which stays in each XCD's 4 MiB L2;
 //   * the 28-term logits are accumulated in fp64 (products of f32 inputs are exact in
 //     fp64, the sum carries ~1e-16 relative error, cf. the reference's float64 sum at
-//     env.py:207-217) and reduced over the 8 lanes with DPP moves (quad_perm xor1/xor2 +
-//     row_half_mirror) -- no LDS traffic, no ds_bpermute;
-//   * the packed [N][29] f32 observation rows of a wave (8 x 116 B = 928 contiguous bytes)
-//     are transposed through a 1-KB LDS tile and leave as 58 fully coalesced 16-B stores;
+//     env.py:207-217) and reduced over the group's lanes with DPP quad_perm moves -- no LDS
+//     traffic, no ds_bpermute;
+//   * the packed [N][29] f32 observation rows of a wave (16 x 116 B = 1856 contiguous bytes)
+//     are transposed through a 2-KB LDS tile and leave as 116 coalesced non-temporal 16-B stores;
 //   * per-env state is two 16-B words (cold: episode tuple, hot: counters) read as group
-//     broadcast loads; the hot word is written back as whole 128-B lines per wave.
+//     broadcast loads; the hot word is written back as whole 128-B lines per wave;
+//   * workgroup -> env-tile mapping is XCD-aware (logical_block); the dense reward precompute
+//     (k_logit_table) is the only MFMA user (fp64 16x16x4).
 //
 // No fallback path exists: if this library is missing the Python package fails to import.
 
@@ -532,8 +534,7 @@ struct ResetArgs {
   int64_t n;
   int64_t gid0;
   ResetCfg rc;
-  int32_t from_tuples;
-  int32_t first;  // 1: state is uninitialised (create): sticky = -1, episode_no = 0
+  int32_t from_tuples;  // 0: device RNG draw, 1: caller's tuples, 2: observe only (state untouched)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {

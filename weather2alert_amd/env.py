@@ -191,9 +191,7 @@ class HeatAlertVecEnv:
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
         self._sticky = [budget] * n  # host mirror of self.budget per env (numpy_parity mode, Q9)
         self._needs_reset = True
-        self._flags = 0
         self._last_opts: dict = {}
-        self._episode_seed = 0
 
     # ------------------------------------------------------------------ plumbing
     def _set_step_mode(self):
