@@ -1,0 +1,57 @@
+"""Host logic on CPU: the NumPy-parity replay of reset() (weather2alert_amd/rng.py) against the golden
+reset tuples captured from the reference, and the errors it mirrors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from weather2alert_amd import rng, tables
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    d = dict(np.load(os.path.join(golden_dir, "mini_traj.npz")))
+    ct = tables.CompiledTables.load_npz(os.path.join(golden_dir, "mini_compiled.npz"))
+    return d, json.loads(str(d["meta_json"])), ct
+
+
+def test_replay_matches_every_golden_reset(gold):
+    d, meta, ct = gold
+    sticky = {}
+    for i, e in enumerate(meta["episodes"]):
+        key, kw = e["env_key"], e["reset"]
+        sticky.setdefault(key, e["ctor"].get("budget"))
+        aug = kw.get("similar_climate_counties", e["ctor"].get("similar_climate_counties", False))
+        w, y_i, li, ci, b, info_loc = rng.numpy_parity_episode(
+            ct, kw["seed"], kw.get("location"), bool(aug), sticky[key], kw.get("budget"),
+            kw.get("sample_budget", False), kw.get("sample_budget_type", "less_than"))
+        sticky[key] = b  # self.budget keeps the (sampled) value (Q9)
+        assert f"{ct.fips_weather[w]}_{ct.years[y_i]}" == e["episode_index"]
+        assert (li, ci, b, info_loc) == (d["location_index"][i], d["coef_index"][i], d["budget"][i], e["info_location"])
+
+
+def test_replay_errors_mirror_the_reference(gold):
+    _, _, ct = gold
+    with pytest.raises(ValueError):
+        rng.numpy_parity_episode(ct, 0, "99999", False, None, None, False, "less_than")
+    import copy
+
+    ct2 = copy.copy(ct)
+    ct2.n_days = ct.n_days.copy()
+    ct2.n_days[:] = 0
+    with pytest.raises(KeyError):
+        rng.numpy_parity_episode(ct2, 0, ct.fips_list[0], False, None, None, False, "less_than")
+    ct3 = copy.copy(ct)
+    ct3.sim_cnt = np.zeros_like(ct.sim_cnt)
+    with pytest.raises(KeyError):
+        rng.numpy_parity_episode(ct3, 0, ct.fips_list[0], True, None, None, False, "less_than")
+
+
+def test_corrected_augmentation_uses_the_drawn_county(gold):
+    _, _, ct = gold
+    loc = "06037"
+    w0, _, li0, _, _, info0 = rng.numpy_parity_episode(ct, 21, loc, True, None, None, False, "less_than")
+    w1, _, li1, _, _, info1 = rng.numpy_parity_episode(ct, 21, loc, True, None, None, False, "less_than", True)
+    assert info0 == info1 and ct.fips_weather[w0] == loc  # faithful: weather of the requested county (Q8)
+    assert ct.fips_list[li1] == info1 and ct.fips_weather[w1] == info1 and li0 < ct.sim_cnt[ct.fips_list.index(loc)]

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _ffi
+from .rng import numpy_parity_episode
 from .spaces import Box, Discrete
 from .tables import CompiledTables, DeviceTables, compile_from_files
 
@@ -337,43 +338,12 @@ class HeatAlertVecEnv:
                 s = int(seed[i])
             else:
                 s = int(seed) + i
-            rng = np.random.default_rng(s)
-            location = self._per_env(loc_o, i)
-            if location is None:
-                location = str(rng.choice(ct.fips_list))  # env.py:151-152
-            if location not in self._fips_pos:
-                raise ValueError(f"{location!r} is not in list")  # env.py:121 list.index
-            county = self._fips_pos[location]
-            if bool(self._per_env(aug_o, i)):
-                if self.reward_path == "table":
-                    raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
-                ns = int(ct.sim_cnt[county])
-                if ns == 0:
-                    raise KeyError(location)  # confounders.loc[fips] (datautils.py:123)
-                li = int(rng.choice(range(ns)))  # env.py:117
-                self._info_location[i] = ct.fips_list[int(ct.similar_list(county)[li])]
-                if "augment" in self.fixes:  # corrected Q8: the drawn county supplies weather and coefficients
-                    county = li = int(ct.similar_list(county)[li])
-                    location = ct.fips_list[county]
-            else:
-                li = county
-                self._info_location[i] = location
-            year = int(rng.choice(ct.years))  # env.py:125
-            w = int(ct.fips_to_weather[county])
-            y_i = ct.years.index(year)
-            if w < 0 or ct.n_days[w * ct.Y + y_i] <= 0:
-                raise KeyError((location, year))  # env.py:127
-            ci = int(rng.integers(0, ct.n_samples))  # env.py:160
-            b = self._sticky[i]
-            if b is None:  # env.py:167-170
-                bk = self._per_env(bud_o, i)
-                b = int(ct.B0[w * ct.Y + y_i]) if bk is None else int(bk)
-            if bool(self._per_env(sb_o, i)):  # env.py:172-177
-                typ = self._per_env(sbt_o, i)
-                if typ == "less_than":
-                    b = int(rng.integers(0, b + 1))
-                elif typ == "centered":
-                    b = int(rng.integers(0.5 * b, 1.5 * b + 1))
+            aug = bool(self._per_env(aug_o, i))
+            if aug and self.reward_path == "table":
+                raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
+            w, y_i, li, ci, b, self._info_location[i] = numpy_parity_episode(
+                ct, s, self._per_env(loc_o, i), aug, self._sticky[i], self._per_env(bud_o, i),
+                bool(self._per_env(sb_o, i)), self._per_env(sbt_o, i), "augment" in self.fixes)
             self._sticky[i] = self._ctor_budget if "budget" in self.fixes else b
             cw[i], yi[i], cc[i], sm[i], bd[i] = w, y_i, li, ci, b
         self._reset_tuples(dict(county_w=cw, year_i=yi, coef_col=cc, sample=sm, budget=bd), mask_t, obs_ptr)

@@ -99,6 +99,16 @@ class CompiledTables:
     def Y(self) -> int:
         return len(self.years)
 
+    def fips_index(self, fips: str) -> int:
+        """fips_list.index(fips) with a cached lookup; ValueError like list.index (env.py:121)."""
+        pos = self.__dict__.get("_fips_pos")
+        if pos is None:
+            pos = self.__dict__["_fips_pos"] = {f: i for i, f in enumerate(self.fips_list)}
+        try:
+            return pos[fips]
+        except KeyError:
+            raise ValueError(f"{fips!r} is not in list") from None
+
     def similar_list(self, county: int) -> np.ndarray:
         return self.sim_idx[self.sim_ptr[county]: self.sim_ptr[county + 1]]
 
