@@ -681,3 +681,27 @@ def test_budget_invariants_at_scale(dev):
     np.testing.assert_allclose(env._final_return.cpu().numpy(), ret.cpu().numpy(), rtol=3e-5)
     assert env.check_status() == 0
     env.close()
+
+
+def test_checkpoint_resume_is_bit_exact(dev):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=8)
+    ct = tables.compile_from_synth(sd)
+    n = 1500
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+    env.reset(seed=2)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = [(torch.rand(n, generator=g) < 0.2).to(torch.int32).to(dev) for _ in range(260)]
+    for a in acts[:120]:
+        env.step(a)
+    ck = env.state_dict()
+    ref = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[120:]]  # crosses an episode boundary (autoreset)
+    other = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+    other.load_state_dict(ck)
+    for a, (o, r, d) in zip(acts[120:], ref):
+        o2, r2, d2, _, _ = other.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    assert torch.equal(env.state()["episode_no"], other.state()["episode_no"])
+    env.close()
+    other.close()

@@ -248,6 +248,41 @@ class HeatAlertVecEnv:
             _ffi.check(self._lib.w2a_get_state(self._h, C.byref(v), self._stream()), "w2a_get_state")
         return out
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> dict:
+        """Everything needed to resume this batch bit-exactly: the packed per-env state (episode tuples,
+        counters, returns, sticky budgets, episode numbers), the last observations and the host-side mirrors.
+        (The reference env has no save/restore)"""
+        return {
+            "state": self._state.clone(), "obs": self._obs.clone(), "final_return": self._final_return.clone(),
+            "reward": self._reward.clone(), "done": self._done.clone(),
+            "host": {"sticky": list(self._sticky), "steps_in_episode": self._steps_in_episode,
+                     "lockstep": self._lockstep, "reset_cfg": self._reset_cfg, "last_opts": dict(self._last_opts),
+                     "needs_reset": self._needs_reset, "info_location": list(getattr(self, "_info_location", [])),
+                     "num_envs": self.num_envs, "env_gid0": self.env_gid0},
+        }
+
+    def load_state_dict(self, sd: dict) -> None:
+        h = sd["host"]
+        if h["num_envs"] != self.num_envs or h["env_gid0"] != self.env_gid0:
+            raise ValueError("state_dict belongs to a different env batch (num_envs / env_gid0 differ)")
+        hdr = self._state[:256].clone()  # slot map written by w2a_create for THIS handle
+        self._state.copy_(sd["state"])
+        self._state[:256].copy_(hdr)
+        self._obs.copy_(sd["obs"])
+        self._final_return.copy_(sd["final_return"])
+        self._reward.copy_(sd["reward"])
+        self._done.copy_(sd["done"])
+        self._sticky = list(h["sticky"])
+        self._steps_in_episode, self._lockstep = h["steps_in_episode"], h["lockstep"]
+        self._reset_cfg, self._last_opts, self._needs_reset = h["reset_cfg"], dict(h["last_opts"]), h["needs_reset"]
+        if h["info_location"]:
+            self._info_location = list(h["info_location"])
+        self._set_step_mode()
+        if self._reset_cfg is not None:
+            with torch.cuda.device(self.device):
+                _ffi.check(self._lib.w2a_set_autoreset(self._h, *self._reset_cfg), "w2a_set_autoreset")
+
     # ------------------------------------------------------------------ reset
     def _opt(self, options, key, default):
         v = None if options is None else options.get(key)
