@@ -348,27 +348,18 @@ struct StepArgs {
 // The in-kernel autoreset variants carry the episode draw and would spill at 64 VGPRs (measured 1.4x slower),
 // so they keep the compiler's own allocation; lock-step batches use the plain variant + k_reset instead.
 // FIXES: compiled-in support for the W2A_FIX_* corrections; the faithful variants carry none of that code.
-template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
-__global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = lane & (LANES - 1);
-  const int grp = lane / LANES;
-  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
-  const int64_t wave_env0 = ((int64_t)lb * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
-  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no barrier is used below
-  const int64_t env = wave_env0 + grp;
-  const bool valid = env < a.n;
-  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: inactive groups shadow the last env, never store
+__device__ __forceinline__ int32_t load_action(const StepArgs &a, uint32_t e) {
+  if (a.act_dtype == W2A_ACT_I32) return reinterpret_cast<const int32_t *>(a.actions)[e];
+  if (a.act_dtype == W2A_ACT_I64) return (int32_t) reinterpret_cast<const int64_t *>(a.actions)[e];
+  return reinterpret_cast<const uint8_t *>(a.actions)[e];
+}
 
-  const uint4 cold = ld_state(a.cold + e);
-  const uint4 hot = ld_state(a.hot + e);
-  int32_t act;
-  if (a.act_dtype == W2A_ACT_I32) act = reinterpret_cast<const int32_t *>(a.actions)[e];
-  else if (a.act_dtype == W2A_ACT_I64) act = (int32_t) reinterpret_cast<const int64_t *>(a.actions)[e];
-  else act = reinterpret_cast<const uint8_t *>(a.actions)[e];
+// One tile = the 16 envs of a wave, one day: everything of env.py:238-262 after the per-env state and action
+// have been loaded (the callers differ in how they schedule those first-hop loads).
+template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
+__device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave, int64_t wave_env0, int lane, int l,
+                                          int grp, bool valid, uint32_t e, const uint4 cold, const uint4 hot,
+                                          int32_t act) {
   uint32_t st_bits = 0;
   if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
 
@@ -515,8 +506,28 @@ __global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) vo
     if (st_bits) atomicOr(a.status, (int)st_bits);
   }
   if (WRITE_OBS) {
-    store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, write_row);
+    store_obs_tile(a.obs, s_tile_wave, wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, write_row);
   }
+}
+
+template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
+__global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & (LANES - 1);
+  const int grp = lane / LANES;
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
+  const int64_t wave_env0 = ((int64_t)lb * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no barrier is used below
+  const int64_t env = wave_env0 + grp;
+  const bool valid = env < a.n;
+  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: inactive groups shadow the last env, never store
+  const uint4 cold = ld_state(a.cold + e);
+  const uint4 hot = ld_state(a.hot + e);
+  const int32_t act = load_action(a, e);
+  step_tile<AUTORESET, WRITE_OBS, TABLE, FIXES>(a, s_tile[wave], wave_env0, lane, l, grp, valid, e, cold, hot, act);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -203,6 +203,7 @@ class HeatAlertVecEnv:
                             (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
 
+
     def _stream(self):
         if self._raw_stream is not None:
             return self._raw_stream(self._dev_index)
