@@ -705,3 +705,32 @@ def test_checkpoint_resume_is_bit_exact(dev):
     assert torch.equal(env.state()["episode_no"], other.state()["episode_no"])
     env.close()
     other.close()
+
+
+def test_device_reset_with_fixed_location_and_host_autoreset(dev, mini):
+    from weather2alert_amd import HeatAlertVecEnv
+
+    d, meta, ct, dt, _ = mini
+    n = 200
+    # device RNG, requested county: weather of that county for every env; augmentation draws the column (Q8)
+    env = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled")
+    env.reset(seed=3, options={"location": "06037", "similar_climate_counties": True})
+    st = env.state()
+    c = ct.fips_list.index("06037")
+    assert (st["county_w"] == int(ct.fips_to_weather[c])).all()
+    assert (st["coef_col"] < int(ct.sim_cnt[c])).all() and len(st["coef_col"].unique()) > 1
+    assert len(st["year_i"].unique()) == ct.Y
+    env.close()
+    # numpy_parity mode autoresets on the host (fresh global-RNG seeds like reset(seed=None), env.py:143-144)
+    e2 = HeatAlertVecEnv(3, tables=dt, device=dev, seed_mode="numpy_parity", autoreset="same_step")
+    e2.reset(seed=[5, 6, 7], options={"location": "06037"})
+    a = torch.zeros(3, dtype=torch.int32, device=dev)
+    np.random.seed(123)
+    for t in range(153):
+        obs, r, done, _, info = e2.step(a)
+    assert done.all() and (e2.state()["t"] == 0).all() and (e2.state()["episode_no"] == 1).all()
+    names = ct.feature_names
+    assert (obs[:, names.index("dos")] == 0).all()  # same-step semantics: the new episode's first observation
+    obs, r, done, _, _ = e2.step(a)
+    assert not done.any() and (e2.state()["t"] == 1).all()
+    e2.close()
