@@ -73,8 +73,8 @@ enum { W2A_BUDGET_FIXED = 0, W2A_BUDGET_LESS_THAN = 1, W2A_BUDGET_CENTERED = 2 }
  *   slots 24..27  run-time fields: alert_lag1, alert_streak, remaining_budget, alert_2wks(agent)
  *   slot   28     25th table-sourced column if the schema has one (else 0)
  *   slot   29     bias input (the table stores 1.0)
- *   slot   30     copy of 'heat_qi' with a zero coefficient: the effectiveness gate
- *                 heat_qi > 0.5 (env.py:218) is read here by lane 7
+ *   slot   30     0/1 flag "heat_qi > 0.5" (the effectiveness gate of env.py:218, decided by the table
+ *                 compiler on the file's float64 value), zero coefficient; kernels test it with > 0.5f
  *   slot   31     zero
  * W rows use the same slots (zero where a slot has no coefficient), so a reward logit is a
  * plain 32-wide dot product. obs_slot[j] maps observation column j (reference order,

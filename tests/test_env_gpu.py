@@ -177,7 +177,7 @@ def test_logit_table_matches_float64_contraction(dev):
     for c in range(ct.S_w):
         rows = slice(c * ct.Y, (c + 1) * ct.Y)
         ref = np.einsum("trk,shk->trsh", X[:, rows][:, :, tab], W[w2f[c]][:, :, tab])
-        closed = ~(ct.X[:, rows, 30] > 0.5)
+        closed = ~(ct.X[:, rows, ct.slot_of["heat_qi"]] > 0.5)
         ref[..., 1][closed] = -np.inf
         got = L[:, rows]
         fin = np.isfinite(ref)

@@ -279,7 +279,9 @@ def compile_from_files(data_dir: str | None, weights: str = "nn_full_medicare_al
             continue
         X[d, r, slot_of[c]] = vals32[keep, j]
     X[d, r, SLOT_BIAS] = 1.0
-    X[d, r, SLOT_GATE] = vals32[keep, columns.index("heat_qi")]
+    # the gate heat_qi > 0.5 (env.py:218) is decided on the file's float64 values, so a value that float32
+    # rounding would move across 0.5 cannot flip it; the kernels test this 0/1 flag with "> 0.5f"
+    X[d, r, SLOT_GATE] = (vals64[keep, columns.index("heat_qi")] > 0.5).astype(np.float32)
     n_days = np.zeros(S_w * Y, np.int64)
     np.add.at(n_days, r, 1)
     B0 = np.zeros(S_w * Y, np.int64)
@@ -308,7 +310,7 @@ def compile_from_synth(d, sorted_keys: bool = True) -> CompiledTables:
             continue
         Xv[..., slot_of[c]] = np.moveaxis(np.asarray(getattr(d, c), np.float32), 2, 0)
     Xv[..., SLOT_BIAS] = 1.0
-    Xv[..., SLOT_GATE] = Xv[..., slot_of["heat_qi"]]
+    Xv[..., SLOT_GATE] = (Xv[..., slot_of["heat_qi"]] > 0.5).astype(np.float32)  # 0/1 gate flag (env.py:218)
     n_days = np.full(S_w * Y, T, np.int64)
     ragged = d.meta.get("n_days_per_episode")  # optional [S_w, Y] episode lengths (0 = pair absent)
     if ragged is not None:
