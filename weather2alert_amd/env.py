@@ -239,15 +239,19 @@ class HeatAlertVecEnv:
 
     def state(self) -> dict[str, torch.Tensor]:
         """Decoded per-env integer state (device tensors)."""
+        return self._state_packed()[1]
+
+    def _state_packed(self):
+        """(one int32 [n_fields, N] buffer, dict of per-field views into it): a single D2H copy fetches all."""
         v = _ffi.StateView()
+        buf = torch.empty((len(_ffi.STATE_FIELDS), self.num_envs), dtype=torch.int32, device=self.device)
         out = {}
-        for k in _ffi.STATE_FIELDS:
-            dt = torch.float32 if k == "episode_return" else torch.int32
-            out[k] = torch.empty(self.num_envs, dtype=dt, device=self.device)
-            setattr(v, k, out[k].data_ptr())
+        for i, k in enumerate(_ffi.STATE_FIELDS):
+            out[k] = buf[i].view(torch.float32) if k == "episode_return" else buf[i]
+            setattr(v, k, buf[i].data_ptr())
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.w2a_get_state(self._h, C.byref(v), self._stream()), "w2a_get_state")
-        return out
+        return buf, out
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
@@ -649,7 +653,9 @@ class HeatAlertEnv:
         return self._v._sticky[0]
 
     def _sync_state(self):
-        st = {k: v.cpu().numpy()[0] for k, v in self._v.state().items()}
+        buf, _ = self._v._state_packed()
+        host = buf.cpu().numpy()[:, 0]  # one device-to-host copy for all fields
+        st = {k: host[i] for i, k in enumerate(_ffi.STATE_FIELDS)}
         ct = self._v.ct
         self.t = int(st["t"])
         self.alert_streak = int(st["streak"])
