@@ -68,3 +68,22 @@ def test_env_refuses_to_run_without_gpu():
         HeatAlertVecEnv(4, tables=ct, device="cuda:0")
     with pytest.raises(RuntimeError):
         HeatAlertVecEnv(4, tables=ct, device="cpu")
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/w2a.h compiles as strict C99 and a C program links libw2a.so and calls the host-only entry
+    points (this is the binding any non-Python host language would use)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "c_abi_check"
+    libdir = os.path.dirname(_ffi.lib_path())
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi_check.c"), "-L", libdir, "-lw2a", f"-Wl,-rpath,{libdir}",
+                    "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert f"sizeof(w2a_tables)={C.sizeof(_ffi.Tables)}" in r.stdout
