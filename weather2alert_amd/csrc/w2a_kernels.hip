@@ -343,7 +343,7 @@ struct StepArgs {
 };
 
 #ifndef W2A_MIN_WAVES
-#define W2A_MIN_WAVES 8  // waves/SIMD the plain step variants are compiled for (<= 64 VGPRs): the kernel is
+#define W2A_MIN_WAVES 7  // waves/SIMD the plain step variants are compiled for (<= 72 VGPRs): the kernel is
 #endif                   // latency-bound and measured faster at full occupancy
 // The in-kernel autoreset variants carry the episode draw and would spill at 64 VGPRs (measured 1.4x slower),
 // so they keep the compiler's own allocation; lock-step batches use the plain variant + k_reset instead.
@@ -420,10 +420,15 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
   } else {
     const float4 *wp = a.tb.W + wrow * (2 * ROWF / 4) + l * QUADS;
     float4 wb[QUADS], we[QUADS];
+    // The effectiveness logit only enters the reward through eff * actual (env.py:221): without an alert today
+    // its coefficient row is not fetched at all (most env-days: alerts are budget-limited) -- half the
+    // coefficient traffic. The lanes of such envs are masked out of the load; the reward is bit-identical.
+    const bool need_eff = actual != 0u;
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
       wb[q] = ld_w(wp + q);
-      we[q] = ld_w(wp + ROWF / 4 + q);
+      we[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (need_eff) we[q] = ld_w(wp + ROWF / 4 + q);
     }
     // env.py:207-217: two 28-term dot products, fp64 accumulation
     zb = 0.0;
@@ -440,7 +445,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
       ze = fma(x2, (double)we[q].z, ze);
       ze = fma(x3, (double)we[q].w, ze);
     }
-    // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds a copy of heat_qi with a zero
+    // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds the 0/1 gate flag with a zero
     // coefficient; a closed gate drives the logit to -inf so that sigmoid() is exactly 0
     if (l == GATE_QUAD / QUADS && !(x[GATE_QUAD % QUADS].z > 0.5f)) ze = -__builtin_inf();
     zb = group_sum(zb);
