@@ -203,9 +203,7 @@ def test_table_path_rejects_augmentation(dev, mini):
                                         sample=0)})
     with pytest.raises(ValueError):
         env.check_status()
-    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto").reward_path == "table"
-    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto",
-                           similar_climate_counties=True).reward_path == "gather"
+    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto").reward_path == "gather"
     env.close()
 
 

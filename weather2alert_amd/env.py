@@ -46,7 +46,8 @@ class HeatAlertVecEnv:
                          terms (works for every episode); "table": logits come from a table precomputed once
                          by a grouped fp64-MFMA GEMM (DeviceTables.build_logit_table) -- less memory traffic
                          per step, but only for episodes whose coefficients are the weather county's own,
-                         i.e. without similar_climate_counties; "auto": table unless augmentation is on.
+                         i.e. without similar_climate_counties; "auto": the faster of the two (currently always
+                         "gather").
     episode_order        "iid" (default): env i keeps its own independent draws, like N reference envs;
                          "sorted": after every (lock-step) reset the envs are relabelled so that env indices
                          follow the coefficient / logit-table row. The batch holds exactly the same multiset of
@@ -118,7 +119,9 @@ class HeatAlertVecEnv:
         if reward_path not in ("gather", "table", "auto"):
             raise ValueError(f"reward_path {reward_path!r}")
         if reward_path == "auto":
-            reward_path = "gather" if self.similar_climate_counties else "table"
+            # measured: since the effectiveness row is fetched only on alert days the row-gather
+            # kernel beats the logit-table kernel at every batch size, so "auto" is the gather path
+            reward_path = "gather"
         if reward_path == "table" and self.similar_climate_counties:
             raise ValueError("reward_path='table' cannot serve similar_climate_counties=True (Q8 pairs a county's "
                              "weather with another county's coefficients); use 'gather'")
