@@ -718,6 +718,11 @@ def test_device_reset_with_fixed_location_and_host_autoreset(dev, mini):
     assert (st["county_w"] == int(ct.fips_to_weather[c])).all()
     assert (st["coef_col"] < int(ct.sim_cnt[c])).all() and len(st["coef_col"].unique()) > 1
     assert len(st["year_i"].unique()) == ct.Y
+    info = env._info()
+    epi, loc = info["episode_index"], info["location"]
+    assert all(x.startswith("06037_") for x in epi) and {int(x[6:]) for x in epi} == set(ct.years)
+    sim = [ct.fips_list[j] for j in ct.similar_list(c)]
+    assert all(l == sim[k] for l, k in zip(loc, st["coef_col"].cpu().numpy()))  # env.py:118 (Q8)
     env.close()
     # numpy_parity mode autoresets on the host (fresh global-RNG seeds like reset(seed=None), env.py:143-144)
     e2 = HeatAlertVecEnv(3, tables=dt, device=dev, seed_mode="numpy_parity", autoreset="same_step")

@@ -585,11 +585,14 @@ class HeatAlertVecEnv:
 
 class _LazyInfo(dict):
     """info dict whose entries are fetched from the device on first access (env.py:228-236).
-    Keys: remaining_budget, at_budget, location_index (coefficient column), county_w, year,
-    feature_names, final_return."""
+    Device tensors: remaining_budget, at_budget, location_index (coefficient column), county_w, year,
+    final_return, t; host values: feature_names, and the reference's string entries episode_index
+    ("<fips>_<year>") and location (env.py:118: under augmentation the fips at the drawn position of the
+    filtered similar-county list) as lists, built only when asked for."""
 
     _KEYS = ("remaining_budget", "at_budget", "location_index", "county_w", "year", "feature_names",
-             "final_return", "t")
+             "final_return", "t", "episode_index", "location")
+    _HOST_KEYS = ("episode_index", "location")
 
     def __init__(self, env: HeatAlertVecEnv):
         super().__init__()
@@ -605,8 +608,29 @@ class _LazyInfo(dict):
                 location_index=st["coef_col"], county_w=st["county_w"], year=years[st["year_i"].long()],
                 feature_names=e.feature_names, final_return=e._final_return, t=st["t"])
 
+    def _host(self, k):
+        e, ct = self._env, self._env.ct
+        cw = super().__getitem__("county_w").cpu().numpy()
+        if k == "episode_index":
+            yr = super().__getitem__("year").cpu().numpy()
+            return [f"{ct.fips_weather[c]}_{y}" for c, y in zip(cw, yr)]
+        if e.seed_mode == "numpy_parity" and getattr(e, "_info_location", None):
+            return list(e._info_location)
+        col = super().__getitem__("location_index").cpu().numpy()
+        # device-RNG episodes: whether the last reset augmented is a property of the reset call
+        aug = bool(e._reset_cfg[2]) if e._reset_cfg is not None else False
+        if not aug or "augment" in e.fixes:
+            return [ct.fips_list[li] for li in col]
+        out = []
+        for c, li in zip(cw, col):  # position li of the filtered similar list of the requested county (Q8)
+            sl = ct.similar_list(ct.fips_index(ct.fips_weather[c]))
+            out.append(ct.fips_list[int(sl[li])])
+        return out
+
     def __getitem__(self, k):
         self._fill()
+        if k in self._HOST_KEYS and not super().__contains__(k):
+            super().__setitem__(k, self._host(k))
         return super().__getitem__(k)
 
     def __contains__(self, k):
