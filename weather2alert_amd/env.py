@@ -98,6 +98,8 @@ class HeatAlertVecEnv:
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("HeatAlertVecEnv needs a ROCm GPU (device='cuda:N'); there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if num_envs <= 0:
             raise ValueError("num_envs must be positive")
         if seed_mode not in ("device", "numpy_parity"):
@@ -112,6 +114,8 @@ class HeatAlertVecEnv:
         self.write_obs = bool(write_obs)
         self._ctor_budget = budget
         if isinstance(tables, DeviceTables):
+            if tables.device != self.device:
+                raise ValueError(f"tables live on {tables.device}, the env on {self.device}")
             self.dtables = tables
         else:
             ct = tables if tables is not None else compile_from_files(data_dir, weights, split, years)
@@ -205,7 +209,6 @@ class HeatAlertVecEnv:
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
                             (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
-
 
     def _stream(self):
         if self._raw_stream is not None:

@@ -335,6 +335,8 @@ class DeviceTables:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DeviceTables needs a ROCm GPU device ('cuda:N'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
         self.X = t(ct.X)
         self.W = t(ct.W)
