@@ -18,10 +18,12 @@
 //     are transposed through a 2-KB LDS tile and leave as 116 coalesced non-temporal 16-B stores;
 //   * per-env state is two 16-B words (cold: episode tuple, hot: counters) read as group
 //     broadcast loads; the hot word is written back as whole 128-B lines per wave;
+//   * the effectiveness coefficient row is fetched only for envs that issue an alert today
+//     (it enters the reward through eff * actual, env.py:221): half the gather traffic;
 //   * workgroup -> env-tile mapping is XCD-aware (logical_block); the dense reward precompute
 //     (k_logit_table) is the only MFMA user (fp64 16x16x4).
 //
-// No fallback path exists: if this library is missing the Python package fails to import.
+// No fallback path exists: without this library (or without a ROCm device) constructing an env raises.
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
