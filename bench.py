@@ -279,8 +279,11 @@ def main():
                                    + ("" if env._dev_auto else " + k_reset once per episode"),
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                          "measured_traffic_gbs": None if traffic is None else traffic / per_launch_s / 1e9,
-                         "note": "achieved uses SURVEY 8d algorithmic bytes; it can exceed the HBM peak because "
-                                 "the day slice of X is served by L2 and W by the Infinity Cache",
+                         "note": "achieved uses SURVEY 8d algorithmic bytes (489 B: what the reference's step reads and "
+                                 "writes). It can exceed the HBM peak because the day slice of X is served by L2 and W "
+                                 "by the Infinity Cache, and because this kernel fetches the 112-B effectiveness row "
+                                 "only on alert days (eff enters the reward through eff*actual); measured_traffic_gbs "
+                                 "is what actually crossed the fabric",
                          "avg_launch_us": per_launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "timing": "HIP events on the launch stream around the timed steps / steps"},
