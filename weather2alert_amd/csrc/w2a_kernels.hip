@@ -38,7 +38,9 @@
 #endif
 #define ROWF 32
 #define QUADS (ROWF / 4 / LANES)  // float4 per lane per 32-float row
-#define BLOCK 256
+#ifndef BLOCK
+#define BLOCK 256  // threads per workgroup (128 / 512 measured within noise of 256)
+#endif
 #define ENVS_PER_BLOCK (BLOCK / LANES)
 #define ENVS_PER_WAVE (64 / LANES)
 #define HDR_BYTES 256
