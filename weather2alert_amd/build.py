@@ -29,7 +29,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     m = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(INC, "w2a.h")]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cuh"))] + [os.path.join(INC, "w2a.h")]
     return any(os.path.getmtime(d) > m for d in deps)
 
 

@@ -1,0 +1,157 @@
+// w2a_rollout.cuh -- k_rollout: on-device policy rollout
+// Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
+#ifndef W2A_W2A_ROLLOUT_CUH
+#define W2A_W2A_ROLLOUT_CUH
+
+// ----------------------------------------------------------------------------------------
+// on-device policy rollout: many days per launch, coefficients kept in registers
+// ----------------------------------------------------------------------------------------
+// Same per-day arithmetic as k_step (env.py:238-262) for up to n_steps days or until the episode ends; the
+// action comes from a policy evaluated in the kernel on what the reference's agent would see: the lagging
+// observation (row of day t-1, Q6), the remaining budget and the day. No observation rows are written; the
+// packed state is advanced so step()/rollout() calls can be mixed.
+struct RolloutArgs {
+  DevTables tb;
+  uint4 *cold;
+  uint4 *hot;
+  int32_t *status;
+  int64_t n;
+  int64_t gid0;
+  w2a_policy pol;
+  int32_t pol_slot;    // table slot of the observed feature (threshold policy)
+  int32_t n_steps;
+  float *ret_out;      // [n] sum of rewards over the days run by this call
+  int32_t *alerts_out; // [n] alerts actually issued by this call
+  int32_t *attempts_over_budget;  // [n] alerts attempted while at budget (nullable)
+  uint32_t *alert_mask;           // [n][mask_words] bit d = alert issued on day d (nullable)
+  int32_t mask_words;
+  float *last_return;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = lane & (LANES - 1);
+  const int grp = lane / LANES;
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);
+  const int64_t wave_env0 = ((int64_t)lb * (BLOCK / 64) + wave) * ENVS_PER_WAVE;
+  if (wave_env0 >= a.n) return;
+  const int64_t env = wave_env0 + grp;
+  const bool valid = env < a.n;
+  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
+  const uint4 cold = a.cold[e];
+  const uint4 hot = a.hot[e];
+  uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
+  uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
+  const uint32_t ndays = D1_NDAYS(hot.y);
+  const int32_t budget = (int32_t)hot.w;
+  bool fin = D1_FIN(hot.y) != 0;
+  float ret_total = __uint_as_float(hot.z);
+  const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+  const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
+  // coefficient rows once per launch, kept as fp64 in registers
+  double wb[4 * QUADS], we[4 * QUADS];
+  {
+    const float4 *wp = a.tb.W + wrow * (2 * ROWF / 4) + l * QUADS;
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+      const float4 b = wp[q], f = wp[ROWF / 4 + q];
+      wb[4 * q] = b.x; wb[4 * q + 1] = b.y; wb[4 * q + 2] = b.z; wb[4 * q + 3] = b.w;
+      we[4 * q] = f.x; we[4 * q + 1] = f.y; we[4 * q + 2] = f.z; we[4 * q + 3] = f.w;
+    }
+  }
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+  float ret = 0.0f;
+  int32_t alerts = 0, over = 0;
+  uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
+  // feature the policy sees on its first day here: row of day max(t-1, 0) (lagging observation, Q6)
+  float feat = 0.0f;
+  if (a.pol.kind == W2A_POLICY_THRESHOLD)
+    feat = Xf[((size_t)((a.pol.obs_lag && t > 0 ? t - 1 : t) * rows_per_day + cold.x)) * ROWF + a.pol_slot];
+  bool active = !fin && valid;
+  for (int s = 0; s < a.n_steps; ++s) {
+    if (!__any(active)) break;
+    // ---- policy
+    int32_t act = 0;
+    const int32_t rem_now = budget - (int32_t)used;
+    if (a.pol.kind == W2A_POLICY_ALWAYS) act = 1;
+    else if (a.pol.kind == W2A_POLICY_BERNOULLI) {
+      const uint32_t u = (uint32_t)(w2a_mix64(pstream + (uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull) >> 32);
+      act = ((float)u * 2.3283064365386963e-10f < a.pol.p) ? 1 : 0;
+    } else if (a.pol.kind == W2A_POLICY_THRESHOLD) act = (feat > a.pol.threshold) ? 1 : 0;
+    else if (a.pol.kind == W2A_POLICY_TABLE) {
+      int32_t rr = rem_now < 0 ? 0 : (rem_now >= a.pol.table_R ? a.pol.table_R - 1 : rem_now);
+      act = a.pol.table[(size_t)t * a.pol.table_R + rr] ? 1 : 0;
+    }
+    if (a.pol.require_budget && rem_now <= 0) act = 0;
+    // ---- env.py:242-250
+    const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
+    const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
+    const uint32_t used2 = used + actual;
+    const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+    const uint32_t day_row = t * rows_per_day + cold.x;
+    float4 x[QUADS];
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
+    const float today = (a.pol.kind == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    const uint32_t fx = a.tb.fixes;
+    const float f_a2w = (float)__popc(hist2);
+    if (l == RT_QUAD / QUADS)
+      x[RT_QUAD % QUADS] = make_float4((t > 0) ? (float)((fx & W2A_FIX_LAG) ? last : actual) : 0.0f, (float)streak,
+                                       (float)(budget - (int32_t)used2), f_a2w);
+    if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
+      set_comp(x, a.tb.slot_hist2w % (4 * QUADS), f_a2w);
+    double zb = 0.0, ze = 0.0;
+#pragma unroll
+    for (int q = 0; q < QUADS; ++q) {
+      const double x0 = (double)x[q].x, x1 = (double)x[q].y, x2 = (double)x[q].z, x3 = (double)x[q].w;
+      zb = fma(x0, wb[4 * q], zb); zb = fma(x1, wb[4 * q + 1], zb);
+      zb = fma(x2, wb[4 * q + 2], zb); zb = fma(x3, wb[4 * q + 3], zb);
+      ze = fma(x0, we[4 * q], ze); ze = fma(x1, we[4 * q + 1], ze);
+      ze = fma(x2, we[4 * q + 2], ze); ze = fma(x3, we[4 * q + 3], ze);
+    }
+    if (l == GATE_QUAD / QUADS && !(x[GATE_QUAD % QUADS].z > 0.5f)) ze = -__builtin_inf();
+    zb = group_sum(zb);
+    ze = group_sum(ze);
+    float r = -(1000.0f / 152.0f) * sigmoid_f32((float)zb) * (1.0f - sigmoid_f32((float)ze) * (float)actual);
+    if ((fx & W2A_FIX_PENALTY) && act == 1 && atb_s) r = -1.0f;
+    if (active) {
+      const bool done = (t + 1 >= ndays);
+      ret += r;
+      ret_total += r;
+      alerts += (int32_t)actual;
+      over += (act == 1 && atb_s) ? 1 : 0;
+      if (a.alert_mask && actual) {
+        const uint32_t wi = t >> 5;
+        if (wi != mask_idx) {
+          if (mask_idx != 0xFFFFFFFFu && l == 0 && mask_idx < (uint32_t)a.mask_words)
+            a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+          mask_idx = wi;
+          mask_word = 0;
+        }
+        mask_word |= 1u << (t & 31);
+      }
+      used = used2; hist = hist2; last = actual; atb = atb_s;
+      if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
+      else { fin = true; active = false; }
+      feat = a.pol.obs_lag ? today : feat;
+    }
+    // lag 1 (faithful): the next decision sees today's row; lag 0 needs tomorrow's row
+    if (a.pol.kind == W2A_POLICY_THRESHOLD && !a.pol.obs_lag && active)
+      feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
+  }
+  if (valid && l == 0) {
+    a.hot[e] = make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
+                          __float_as_uint(ret_total), (uint32_t)budget);
+    if (a.ret_out) a.ret_out[e] = ret;
+    if (a.alerts_out) a.alerts_out[e] = alerts;
+    if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
+    if (a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+      a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+    if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
+  }
+}
+
+#endif  // W2A_W2A_ROLLOUT_CUH

@@ -1,0 +1,26 @@
+// w2a_sort.cuh -- relabelling sort for episode_order="sorted"
+// Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
+#ifndef W2A_W2A_SORT_CUH
+#define W2A_W2A_SORT_CUH
+
+// ----------------------------------------------------------------------------------------
+// episode_order="sorted": relabel envs so that neighbours share coefficient / logit rows
+// ----------------------------------------------------------------------------------------
+__global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, int64_t n, int by_weather_row) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4 c = cold[i];
+  // gather path: coefficient row (column, draw) major, weather row minor; table path: weather row, then draw
+  keys[i] = by_weather_row ? (((uint64_t)c.x << SAMPLE_BITS) | W_SAMPLE(c.y)) : (((uint64_t)c.y << 32) | c.x);
+  idx[i] = (uint32_t)i;
+}
+__global__ void k_permute_state(const uint4 *cold, const uint4 *hot, const uint32_t *idx, uint4 *cold_o, uint4 *hot_o,
+                                int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t j = idx[i];
+  cold_o[i] = cold[j];
+  hot_o[i] = hot[j];
+}
+
+#endif  // W2A_W2A_SORT_CUH

@@ -2,7 +2,7 @@
 
 ``HeatAlertVecEnv`` steps ``num_envs`` independent copies of the reference's
 ``weather2alert.env.HeatAlertEnv`` (``/root/reference/src/weather2alert/env.py``) inside
-hand-written gfx950 kernels (``csrc/w2a_kernels.hip`` through the C ABI of
+hand-written gfx950 kernels (``csrc/*.cuh``, ``csrc/w2a_kernels.hip`` through the C ABI of
 ``include/w2a.h``). ``HeatAlertEnv`` is the ``num_envs=1`` drop-in with the reference's
 exact constructor / ``reset`` / ``step`` signatures and NumPy-seed parity.
 
