@@ -255,13 +255,16 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
 __device__ __forceinline__ void store_obs_tile(float *__restrict__ obs, float *tile, int64_t wave_env0, int64_t n,
                                                int n_obs, int lane, int grp, const float4 *x, const int4 *so,
                                                bool write_me) {
-  float *row = tile + grp * n_obs;
+  // branch-free scatter: slots that are not observation columns (bias, gate flag, pads; so < 0) go to a scratch
+  // word behind the packed rows (the tile has ENVS_PER_WAVE*32 floats, the rows use ENVS_PER_WAVE*n_obs <= 30*16)
+  const int base = grp * n_obs;
+  const int trash = ENVS_PER_WAVE * n_obs + (lane & 15);
 #pragma unroll
   for (int q = 0; q < QUADS; ++q) {
-    if (so[q].x >= 0) row[so[q].x] = x[q].x;
-    if (so[q].y >= 0) row[so[q].y] = x[q].y;
-    if (so[q].z >= 0) row[so[q].z] = x[q].z;
-    if (so[q].w >= 0) row[so[q].w] = x[q].w;
+    tile[so[q].x >= 0 ? base + so[q].x : trash] = x[q].x;
+    tile[so[q].y >= 0 ? base + so[q].y : trash] = x[q].y;
+    tile[so[q].z >= 0 ? base + so[q].z : trash] = x[q].z;
+    tile[so[q].w >= 0 ? base + so[q].w : trash] = x[q].w;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

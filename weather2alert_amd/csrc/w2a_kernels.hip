@@ -80,7 +80,8 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
     return fail(W2A_ERR_ARG, "w2a_create: L, Wendo and weather_to_fips must be given together");
   if (((uintptr_t)t->L & 15) || ((uintptr_t)t->Wendo & 15))
     return fail(W2A_ERR_STATE, "w2a_create: L and Wendo must be 16-B aligned");
-  if (t->n_obs <= 0 || t->n_obs > W2A_ROW_FLOATS) return fail(W2A_ERR_SCHEMA, "w2a_create: n_obs must be in 1..32");
+  if (t->n_obs <= 0 || t->n_obs > W2A_ROW_FLOATS - 1)
+    return fail(W2A_ERR_SCHEMA, "w2a_create: n_obs must be in 1..31 (the observation tile keeps one scratch column)");
   if (state_bytes < w2a_state_bytes(num_envs)) return fail(W2A_ERR_STATE, "w2a_create: state buffer too small");
   if (((uintptr_t)state & 255) || ((uintptr_t)t->X & 15) || ((uintptr_t)t->W & 15))
     return fail(W2A_ERR_STATE, "w2a_create: state must be 256-B aligned, X and W 16-B aligned");
