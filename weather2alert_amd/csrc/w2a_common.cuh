@@ -17,9 +17,6 @@
 #ifndef W2A_NT_OBS
 #define W2A_NT_OBS 1  // observation rows leave with non-temporal stores (they are not re-read by the env)
 #endif
-#ifndef W2A_NT_STATE
-#define W2A_NT_STATE 0  // A/B: non-temporal loads/stores for the streamed per-env state, actions, reward, done
-#endif
 #ifndef W2A_NT_W
 #define W2A_NT_W 0      // A/B: non-temporal loads for the gathered coefficient rows
 #endif
@@ -38,22 +35,6 @@ __device__ __forceinline__ uint32_t logical_block(uint32_t b, uint32_t per_xcd) 
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_state(const uint4 *p) {
-#if W2A_NT_STATE
-  v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
-  return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void st_state(uint4 *p, uint4 v) {
-#if W2A_NT_STATE
-  v4u w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<v4u *>(p));
-#else
-  *p = v;
-#endif
-}
 __device__ __forceinline__ float4 ld_w(const float4 *p) {
 #if W2A_NT_W
   v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
@@ -68,11 +49,42 @@ __device__ __forceinline__ float4 ld_w(const float4 *p) {
 // ----------------------------------------------------------------------------------------
 // packed state
 // ----------------------------------------------------------------------------------------
-// cold (uint4): x = ep_row (county_w*Y + year_i), y = coef_col << 12 | sample (n_samples <= 4096),
-//               z = sticky budget (int, -1 unset), w = episode number
-// hot  (uint4): x = dyn0: t[0:10) used[10:20) streak[20:30) last_actual[30] at_budget[31]
-//               y = dyn1: hist14[0:14) n_days[16:26) finished[31]
-//               z = episode return (f32 bits), w = budget (int)
+// Three arrays (40 B per env; a step streams 24 B in and 12 B out):
+//   cold  (uint4, reset-time record, not read by the plain step kernel):
+//           x = ep_row (county_w*Y + year_i), y = coef_col << 12 | sample (n_samples <= 4096),
+//           z = sticky budget (int, -1 unset), w = episode number
+//   stepc (3 x u32, read-only while an episode runs): budget (int), ep_row, ep_w  (copies of cold.x/.y)
+//   hot3  (3 x u32, read and written every step):
+//           dyn0: t[0:10) used[10:20) streak[20:30) last_actual[30] at_budget[31]
+//           dyn1: hist14[0:14) n_days[16:26) finished[31]
+//           episode return (f32 bits)
+// Kernels work on the logical views  cold = {ep_row, ep_w, sticky, episode_no},  hot = {dyn0, dyn1, ret, budget}.
+struct u3 { uint32_t a, b, c; };
+struct StateArrays {
+  uint4 *cold;
+  u3 *hot3;
+  u3 *stepc;
+};
+// per-step view: hot complete, cold.x/.y valid (cold.z/.w = 0: load_cold() when the sticky budget / episode
+// number are needed)
+__device__ __forceinline__ void load_step_state(const StateArrays &s, uint32_t e, uint4 &cold, uint4 &hot) {
+  const u3 h = s.hot3[e];
+  const u3 c = s.stepc[e];
+  hot = make_uint4(h.a, h.b, h.c, c.a);
+  cold = make_uint4(c.b, c.c, 0u, 0u);
+}
+__device__ __forceinline__ uint4 load_cold(const StateArrays &s, uint32_t e) { return s.cold[e]; }
+__device__ __forceinline__ void store_hot(const StateArrays &s, uint32_t e, const uint4 hot) {
+  u3 h; h.a = hot.x; h.b = hot.y; h.c = hot.z;
+  s.hot3[e] = h;
+}
+// a new episode: all three arrays
+__device__ __forceinline__ void store_episode(const StateArrays &s, uint32_t e, const uint4 cold, const uint4 hot) {
+  s.cold[e] = cold;
+  u3 c; c.a = hot.w; c.b = cold.x; c.c = cold.y;
+  s.stepc[e] = c;
+  store_hot(s, e, hot);
+}
 #define D0_T(d) ((d) & 1023u)
 #define D0_USED(d) (((d) >> 10) & 1023u)
 #define D0_STREAK(d) (((d) >> 20) & 1023u)
@@ -135,8 +147,7 @@ struct w2a_env {
   int64_t n;
   int64_t gid0;
   const int32_t *slot_obs;  // [32] slot -> obs column (-1 none), in the state header
-  uint4 *cold;
-  uint4 *hot;
+  StateArrays st;
   int32_t *status;
   ResetCfg autoreset;
   int has_autoreset;

@@ -56,7 +56,7 @@ const char *w2a_last_error(void) { return g_err; }
 
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
-  size_t b = HDR_BYTES + (size_t)num_envs * 32;
+  size_t b = HDR_BYTES + (size_t)num_envs * 40;  // cold 16 + hot3 12 + stepc 12
   return (b + 255) & ~(size_t)255;
 }
 
@@ -111,8 +111,9 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->n = num_envs;
   h->gid0 = env_gid0;
   h->slot_obs = reinterpret_cast<const int32_t *>(state);
-  h->cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
-  h->hot = h->cold + num_envs;
+  h->st.cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
+  h->st.hot3 = reinterpret_cast<u3 *>(h->st.cold + num_envs);
+  h->st.stepc = h->st.hot3 + num_envs;
   h->status = status;
   h->has_autoreset = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
@@ -120,7 +121,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
   if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: header upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
   int64_t blocks = (num_envs + 255) / 256;
-  hipLaunchKernelGGL(k_init_state, dim3((unsigned)blocks), dim3(256), 0, 0, h->cold, h->hot, num_envs);
+  hipLaunchKernelGGL(k_init_state, dim3((unsigned)blocks), dim3(256), 0, 0, h->st, num_envs);
   hipError_t e3 = hipDeviceSynchronize();
   if (e3 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernel failed: %s", hipGetErrorString(e3)); }
   *out = h;
@@ -136,7 +137,7 @@ static unsigned grid_for(int64_t n) {
 }
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
-  a.tb = env->tb; a.slot_obs = env->slot_obs; a.cold = env->cold; a.hot = env->hot;
+  a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
   hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
@@ -198,7 +199,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
   StepArgs a;
   memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.slot_obs = env->slot_obs; a.cold = env->cold; a.hot = env->hot;
+  a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
   dim3 grid(grid_for(env->n)), block(BLOCK);
@@ -269,7 +270,8 @@ static size_t cub_sort_bytes(int64_t n) {
 size_t w2a_sort_workspace_bytes(int64_t num_envs) {
   if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
   size_t n = (size_t)num_envs;
-  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) * 2 + align256(cub_sort_bytes(num_envs));
+  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 +
+         align256(cub_sort_bytes(num_envs));
 }
 
 int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream) {
@@ -283,17 +285,21 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
   uint32_t *i_out = (uint32_t *)p; p += align256(4 * n);
   uint4 *cold_t = (uint4 *)p;      p += align256(16 * n);
-  uint4 *hot_t = (uint4 *)p;       p += align256(16 * n);
+  u3 *hot_t = (u3 *)p;             p += align256(12 * n);
+  u3 *stepc_t = (u3 *)p;           p += align256(12 * n);
   size_t cub_bytes = cub_sort_bytes(env->n);
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->cold, k_in, i_in, env->n, by_weather_row);
+  hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n, by_weather_row);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
-  hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->cold, env->hot, i_out, cold_t, hot_t, env->n);
+  StateArrays tmp;
+  tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t;
+  hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->st, i_out, tmp, env->n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(env->cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(env->hot, hot_t, 16 * n, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
   return W2A_OK;
 }
 
@@ -330,7 +336,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   if (alert_mask && mask_words * 32 < env->tb.T) return fail(W2A_ERR_ARG, "w2a_rollout: alert_mask needs ceil(T/32) words per env");
   RolloutArgs a;
   memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.cold = env->cold; a.hot = env->hot; a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
+  a.tb = env->tb; a.st = env->st; a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
   a.pol = *policy;
   a.pol_slot = 0;
   if (policy->kind == W2A_POLICY_THRESHOLD) {
@@ -351,8 +357,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
   if (!env || !view) return fail(W2A_ERR_ARG, "w2a_get_state: NULL argument");
   int64_t blocks = (env->n + 255) / 256;
-  hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->cold, env->hot,
-                     env->n, env->tb.Y, env->tb.n_samples, *view);
+  hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->st, env->n, env->tb.Y, env->tb.n_samples, *view);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }

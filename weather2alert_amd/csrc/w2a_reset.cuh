@@ -9,8 +9,7 @@
 struct ResetArgs {
   DevTables tb;
   const int32_t *slot_obs;
-  uint4 *cold;
-  uint4 *hot;
+  StateArrays st;
   const int32_t *county_w, *year_i, *coef_col, *sample, *budget;  // host-tuple mode
   const uint8_t *mask;
   float *obs;
@@ -35,12 +34,13 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
   const bool sel = a.mask ? (a.mask[e] != 0) : true;
-  uint4 cold = a.cold[e];
+  uint4 cold = load_cold(a.st, e);
   uint32_t bad = 0;
   Episode ep;
   if (a.from_tuples == 2) {
     // observe only (w2a_observe): first observation of an already reset env, state untouched
-    const uint4 hot = a.hot[e];
+    uint4 c2, hot;
+    load_step_state(a.st, e, c2, hot);
     ep.ep_row = cold.x;
     ep.budget = (int32_t)hot.w;
     if (D0_T(hot.x) != 0) bad = 4;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     set_comp(x, a.tb.slot_hist2w % (4 * QUADS), 0.0f);  // the agent's (empty) history replaces the column
   if (valid && sel && l == 0) {
     if (a.from_tuples != 2) {
-      a.cold[e] = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
-      a.hot[e] = make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget);
+      store_episode(a.st, e, make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1),
+                    make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
     }
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
@@ -85,19 +85,18 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }
 
-__global__ void k_init_state(uint4 *cold, uint4 *hot, int64_t n) {
+__global__ void k_init_state(StateArrays st, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    cold[i] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);  // sticky = -1, episode_no = -1 (first reset -> 0)
-    hot[i] = make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u);
-  }
+  if (i < n)  // sticky = -1, episode_no = -1 (first reset -> 0); finished, so a step before reset() is flagged
+    store_episode(st, (uint32_t)i, make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u));
 }
 
-__global__ void k_get_state(const uint4 *cold, const uint4 *hot, int64_t n, int32_t Y, int32_t n_samples,
-                            w2a_state_view v) {
+__global__ void k_get_state(StateArrays st, int64_t n, int32_t Y, int32_t n_samples, w2a_state_view v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint4 c = cold[i], h = hot[i];
+  uint4 c2, h;
+  load_step_state(st, (uint32_t)i, c2, h);
+  const uint4 c = load_cold(st, (uint32_t)i);
   if (v.t) v.t[i] = (int32_t)D0_T(h.x);
   if (v.used) v.used[i] = (int32_t)D0_USED(h.x);
   if (v.streak) v.streak[i] = (int32_t)D0_STREAK(h.x);

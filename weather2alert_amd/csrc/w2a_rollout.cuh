@@ -12,8 +12,7 @@
 // packed state is advanced so step()/rollout() calls can be mixed.
 struct RolloutArgs {
   DevTables tb;
-  uint4 *cold;
-  uint4 *hot;
+  StateArrays st;
   int32_t *status;
   int64_t n;
   int64_t gid0;
@@ -40,8 +39,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
-  const uint4 cold = a.cold[e];
-  const uint4 hot = a.hot[e];
+  uint4 c2, hot;
+  load_step_state(a.st, e, c2, hot);
+  const uint4 cold = load_cold(a.st, e);
   uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
   uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
   const uint32_t ndays = D1_NDAYS(hot.y);
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
       feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
   }
   if (valid && l == 0) {
-    a.hot[e] = make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
-                          __float_as_uint(ret_total), (uint32_t)budget);
+    store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
+                                  __float_as_uint(ret_total), (uint32_t)budget));
     if (a.ret_out) a.ret_out[e] = ret;
     if (a.alerts_out) a.alerts_out[e] = alerts;
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;

@@ -14,13 +14,13 @@ __global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, in
   keys[i] = by_weather_row ? (((uint64_t)c.x << SAMPLE_BITS) | W_SAMPLE(c.y)) : (((uint64_t)c.y << 32) | c.x);
   idx[i] = (uint32_t)i;
 }
-__global__ void k_permute_state(const uint4 *cold, const uint4 *hot, const uint32_t *idx, uint4 *cold_o, uint4 *hot_o,
-                                int64_t n) {
+__global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArrays dst, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t j = idx[i];
-  cold_o[i] = cold[j];
-  hot_o[i] = hot[j];
+  dst.cold[i] = src.cold[j];
+  dst.hot3[i] = src.hot3[j];
+  dst.stepc[i] = src.stepc[j];
 }
 
 #endif  // W2A_W2A_SORT_CUH

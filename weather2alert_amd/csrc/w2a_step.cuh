@@ -9,8 +9,7 @@
 struct StepArgs {
   DevTables tb;
   const int32_t *slot_obs;
-  uint4 *cold;
-  uint4 *hot;
+  StateArrays st;
   const void *actions;
   float *obs;
   float *reward;
@@ -177,17 +176,12 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     }
   }
   if (valid && l == 0) {
-    st_state(a.hot + e, hot2);
-#if W2A_NT_STATE
-    __builtin_nontemporal_store(r, a.reward + e);
-    __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), a.done + e);
-#else
+    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2);
+    else store_hot(a.st, e, hot2);
     a.reward[e] = r;
     a.done[e] = done ? 1 : 0;
-#endif
     if (done) {
       if (a.last_return) a.last_return[e] = ret;
-      if (AUTORESET) a.cold[e] = cold2;
     }
     if (st_bits) atomicOr(a.status, (int)st_bits);
   }
@@ -210,8 +204,13 @@ __global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) vo
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: inactive groups shadow the last env, never store
-  const uint4 cold = ld_state(a.cold + e);
-  const uint4 hot = ld_state(a.hot + e);
+  uint4 cold, hot;
+  load_step_state(a.st, e, cold, hot);
+  if (AUTORESET) {  // the episode draw needs the sticky budget and the episode number
+    const uint4 full = load_cold(a.st, e);
+    cold.z = full.z;
+    cold.w = full.w;
+  }
   const int32_t act = load_action(a, e);
   step_tile<AUTORESET, WRITE_OBS, TABLE, FIXES>(a, s_tile[wave], wave_env0, lane, l, grp, valid, e, cold, hot, act);
 }
