@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS))
     p.add_argument("--num-envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
+    p.add_argument("--obs-f16", action="store_true", help="opt-in half-precision observations (58 instead of 116 B/env)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the reported extras (sorted episode order)")
     p.add_argument("--seed", type=int, default=0)
@@ -189,7 +190,8 @@ def main():
         dt.build_logit_table(timed=True)
     env = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, env_gid0=rank * n,
                           write_obs=not args.no_obs, reward_path=rpath, episode_order=args.episode_order,
-                          lockstep=False if args.graph else None)
+                          lockstep=False if args.graph else None,
+                          obs_dtype=torch.float16 if args.obs_f16 else torch.float32)
     gather = wdist.ReturnGatherer(n, device)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
@@ -270,6 +272,7 @@ def main():
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
                        "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
                        "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
+                       "obs_dtype": "f16" if args.obs_f16 else "f32",
                        "logit_table_build_ms": dt.logit_build_ms,
                        "logit_table_gb": None if dt.L is None else dt.L.numel() * 8 / 1e9,
                        "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},

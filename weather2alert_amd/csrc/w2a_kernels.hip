@@ -116,6 +116,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.stepc = h->st.hot3 + num_envs;
   h->status = status;
   h->has_autoreset = 0;
+  h->obs_f16 = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -138,7 +139,7 @@ static unsigned grid_for(int64_t n) {
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
-  a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
+  a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.obs_f16 = env->obs_f16;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
   hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
@@ -202,6 +203,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
+  a.obs_f16 = env->obs_f16;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
 #define W2A_LAUNCH(AR, OB, TB) \
@@ -300,6 +302,13 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  return W2A_OK;
+}
+
+int w2a_set_obs_format(w2a_env *env, int format) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_set_obs_format: NULL handle");
+  if (format != W2A_OBS_F32 && format != W2A_OBS_F16) return fail(W2A_ERR_ARG, "w2a_set_obs_format: unknown format");
+  env->obs_f16 = (format == W2A_OBS_F16) ? 1 : 0;
   return W2A_OK;
 }
 

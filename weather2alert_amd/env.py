@@ -66,6 +66,8 @@ class HeatAlertVecEnv:
                          alert_lag1 is yesterday's action), "penalty" (Q5: -1 for an alert attempted at budget),
                          "obs" (Q6: step() returns the next day's row), "augment" (Q8: the drawn similar county
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
+    obs_dtype            torch.float32 (default, bit-exact table values) or torch.float16 (opt-in: observations are
+                         rounded to half on the way out -- half the bytes of the largest stream of a step).
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -93,6 +95,7 @@ class HeatAlertVecEnv:
         lockstep: bool | None = None,
         faithful: bool = True,
         fixes: set | list | None = None,
+        obs_dtype: torch.dtype = torch.float32,
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -160,7 +163,9 @@ class HeatAlertVecEnv:
             nbytes = self._lib.w2a_state_bytes(n)
             self._state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._obs = torch.zeros((n, ct.n_obs), dtype=torch.float32, device=dev)
+            if obs_dtype not in (torch.float32, torch.float16):
+                raise ValueError("obs_dtype must be torch.float32 or torch.float16")
+            self._obs = torch.zeros((n, ct.n_obs), dtype=obs_dtype, device=dev)
             self._reward = torch.zeros(n, dtype=torch.float32, device=dev)
             self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
             self._final_return = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -169,6 +174,8 @@ class HeatAlertVecEnv:
             _ffi.check(self._lib.w2a_create(C.byref(self.dtables.struct), n, self.env_gid0, self._state.data_ptr(),
                                             nbytes, self._status.data_ptr(), C.byref(h)), "w2a_create")
         self._h = h
+        if obs_dtype == torch.float16:
+            _ffi.check(self._lib.w2a_set_obs_format(h, _ffi.OBS_F16), "w2a_set_obs_format")
         bits = sum(_ffi.FIX_BITS[k] for k in self.fixes if k in _ffi.FIX_BITS)
         if bits:
             _ffi.check(self._lib.w2a_set_semantics(h, bits), "w2a_set_semantics")
