@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     if (l == GATE_QUAD / QUADS && !(x[GATE_QUAD % QUADS].z > 0.5f)) ze = -__builtin_inf();
     zb = group_sum(zb);
     ze = group_sum(ze);
-    float r = -(1000.0f / 152.0f) * sigmoid_f32((float)zb) * (1.0f - sigmoid_f32((float)ze) * (float)actual);
+    float r = reward_from_logits(zb, ze, actual);
     if ((fx & W2A_FIX_PENALTY) && act == 1 && atb_s) r = -1.0f;
     if (active) {
       const bool done = (t + 1 >= ndays);

@@ -132,10 +132,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     zb = group_sum(zb);
     ze = group_sum(ze);
   }
-  const float base = sigmoid_f32((float)zb);
-  const float eff = sigmoid_f32((float)ze);
-  // env.py:221
-  float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  float r = reward_from_logits(zb, ze, actual);  // env.py:211-221
   if ((fx & W2A_FIX_PENALTY) && act == 1 && atb) r = -1.0f;  // env.py:223-224 made live (dead in the reference, Q5)
 
   const bool done = (t + 1 >= ndays);  // env.py:256
