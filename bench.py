@@ -47,8 +47,8 @@ ALGO_BYTES_TABLE = 305  # SURVEY §8d logit-table path
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=306)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=1530, help="timed steps (default: 10 episodes, SURVEY §8d)")
+    p.add_argument("--warmup", type=int, default=153, help="untimed steps (default: 1 episode)")
     p.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS))
     p.add_argument("--num-envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
