@@ -29,7 +29,8 @@ def main():
     # 1. rocprofv3 --kernel-trace --stats summary of `python3 bench.py` (names trimmed)
     ks = glob.glob(os.path.join(GO, f"prof_kt_{a.workload}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        rows = list(csv.reader(open(ks[0])))
+        ks.sort(key=os.path.getmtime)  # gpurun merges every session's files into gpurun_out/: take the newest
+        rows = list(csv.reader(open(ks[-1])))
         with open(os.path.join(out, f"kernel_stats_{a.workload}.csv"), "w", newline="") as f:
             w = csv.writer(f)
             for r in rows:
@@ -46,7 +47,9 @@ def main():
     # calibration from the raw CSVs: the 1 GiB copy / fill launches are the big ones
     calib = {}
     for name, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
-        for f in glob.glob(os.path.join(GO, f"{name}_{a.workload}", "**", "*counter_collection.csv"), recursive=True):
+        cc = sorted(glob.glob(os.path.join(GO, f"{name}_{a.workload}", "**", "*counter_collection.csv"),
+                              recursive=True), key=os.path.getmtime)
+        for f in cc[-1:]:
             per = {}
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == ctr:
