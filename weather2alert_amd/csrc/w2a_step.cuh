@@ -83,11 +83,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
   if (TABLE) {
     // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
     // add the four run-time terms. Every lane of the group computes the same value (broadcast loads).
-#ifdef W2A_EXP_L_DAY0  // timing experiment only (wrong results): every day reads the day-0 slice, which stays cached
-    const double2 lv = a.tb.L[(size_t)cold.x * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y)];
-#else
     const double2 lv = a.tb.L[(size_t)day_row * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y)];
-#endif
     const float4 qb = a.tb.Wendo[wrow * 2];
     const float4 qe = a.tb.Wendo[wrow * 2 + 1];
     zb = fma((double)f_lag1, (double)qb.x, lv.x);
