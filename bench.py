@@ -174,6 +174,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        print(f"bench.py: --gpus {args.gpus} needs one process per GPU (python -m torch.distributed.run --nnodes=1 "
+              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...); running on 1 GPU",
+              file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if args.backend == 'gloo' else local}")
     torch.cuda.set_device(device)
