@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the reported extras (sorted episode order)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: the workload's env count per GPU (default); strong: that count split over the GPUs")
     p.add_argument("--graph", type=int, default=0,
                    help="capture this many consecutive step() calls into one hipGraph and replay it (launch-bound "
                         "small batches); the timed region still runs exactly --steps steps")
@@ -185,6 +187,11 @@ def main():
 
     wname, n_default, augment, rpath, desc = WORKLOADS[args.workload]
     n = args.num_envs or n_default
+    if args.scaling == "strong":
+        start, stop = wdist.shard_range(n, rank, world)
+        if (stop - start) * world != n:
+            raise SystemExit("--scaling strong needs an env count divisible by the number of GPUs")
+        n = stop - start
     t_setup = time.perf_counter()
     sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
                           extra_confounder_fips=60)
@@ -270,7 +277,7 @@ def main():
         out = {
             "metric": "env_steps_per_sec", "value": total_env_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64" , "data": "synthetic",
             "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
