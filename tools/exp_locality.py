@@ -4,7 +4,6 @@ with (a) random episode tuples, (b) the same tuples sorted by (coef_col, sample)
 for every env (best-case locality), with and without the observation write, gather vs table."""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
