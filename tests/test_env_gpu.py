@@ -799,3 +799,36 @@ def test_half_precision_observations_opt_in(dev):
         assert torch.equal(o16, o32.half()) and torch.equal(r16, r32) and torch.equal(d16, d32)
     a32.close()
     a16.close()
+
+
+def test_other_schema_parity(dev):
+    """A schema with one exogenous feature fewer (n_obs = 28): kernels, observation order and rewards still
+    match the oracle, which derives everything from the column / key names as well."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=12, years=[2006, 2007], n_samples=4, seed=23)
+    j = sd.meta["exo_cols"].index("holiday")
+    sd.exo = np.delete(sd.exo, j, axis=3)
+    sd.meta["exo_cols"] = [c for c in sd.meta["exo_cols"] if c != "holiday"]
+    sd.weights = {k: v for k, v in sd.weights.items() if not k.endswith("_holiday")}
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n = 500
+    rng = np.random.default_rng(0)
+    county = rng.integers(0, ct.S, n)
+    ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
+              sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 9, n))
+    for path in ("gather", "table"):
+        env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_path=path)
+        obs, _ = env.reset(options={"episodes": ep})
+        assert obs.shape == (n, 28)
+        obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
+        np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        r2 = np.random.default_rng(1)
+        for t in range(153):
+            a = (r2.random(n) < 0.2).astype(np.int32)
+            obs, r, done, _, _ = env.step(torch.as_tensor(a, device=dev))
+            obs_o, r_o, done_o, _ = V.step(a)
+            assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+            np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        env.close()

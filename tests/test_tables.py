@@ -138,3 +138,25 @@ def test_ragged_real_artefacts(tmp_path, mini_root):
     # years=[...] restricts valid_years like the ctor argument (env.py:32,104)
     ct2 = tables.compile_from_files(str(root), "linear", years=[2008, 2006])
     assert ct2.years == [2008, 2006] and ct2.Y == 2
+
+
+def _drop_feature(sd, name):
+    j = sd.meta["exo_cols"].index(name)
+    sd.exo = np.delete(sd.exo, j, axis=3)
+    sd.meta["exo_cols"] = [c for c in sd.meta["exo_cols"] if c != name]
+    sd.weights = {k: v for k, v in sd.weights.items() if k not in (f"baseline_{name}", f"effectiveness_{name}")}
+    return sd
+
+
+def test_slot_layout_is_data_driven():
+    """Nothing about the feature list is hard-coded: a schema without 'holiday' compiles to n_obs = 28 with the
+    remaining columns in file order; a schema with too many table-sourced columns is refused."""
+    sd = _drop_feature(synth.make_synth("linear", n_fips=8, years=[2006], n_samples=2, seed=0), "holiday")
+    ct = tables.compile_from_synth(sd)
+    assert ct.n_obs == 28 and "holiday" not in ct.columns and ct.feature_names[-1] == "alert_2wks"
+    assert [ct.slot_of[c] for c in ct.columns[:20]] == list(range(20))
+    sd2 = synth.make_synth("linear", n_fips=8, years=[2006], n_samples=2, seed=0)
+    sd2.exo = np.concatenate([sd2.exo, sd2.exo[..., :1]], axis=3)
+    sd2.meta["exo_cols"] = sd2.meta["exo_cols"] + ["extra_feature"]
+    with pytest.raises(tables.SchemaError):
+        tables.compile_from_synth(sd2)
