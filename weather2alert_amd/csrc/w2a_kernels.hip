@@ -56,7 +56,7 @@ const char *w2a_last_error(void) { return g_err; }
 
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
-  size_t b = HDR_BYTES + (size_t)num_envs * 40;  // cold 16 + hot3 12 + stepc 12
+  size_t b = HDR_BYTES + (size_t)num_envs * 72 + 16;  // cold 16 + hot3 12 + stepc 12 + (16-B alignment) + rtw 32
   return (b + 255) & ~(size_t)255;
 }
 
@@ -114,6 +114,8 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
   h->st.hot3 = reinterpret_cast<u3 *>(h->st.cold + num_envs);
   h->st.stepc = h->st.hot3 + num_envs;
+  // 16-B aligned: HDR (256) + 40*N bytes, N*40 % 16 == 0 needs N even -> round the offset up instead
+  h->st.rtw = t->Wendo ? reinterpret_cast<float4 *>(((uintptr_t)(h->st.stepc + num_envs) + 15) & ~(uintptr_t)15) : nullptr;
   h->status = status;
   h->has_autoreset = 0;
   h->obs_f16 = 0;
@@ -272,7 +274,7 @@ static size_t cub_sort_bytes(int64_t n) {
 size_t w2a_sort_workspace_bytes(int64_t num_envs) {
   if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
   size_t n = (size_t)num_envs;
-  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 +
+  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 + align256(32 * n) +
          align256(cub_sort_bytes(num_envs));
 }
 
@@ -289,6 +291,7 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   uint4 *cold_t = (uint4 *)p;      p += align256(16 * n);
   u3 *hot_t = (u3 *)p;             p += align256(12 * n);
   u3 *stepc_t = (u3 *)p;           p += align256(12 * n);
+  float4 *rtw_t = (float4 *)p;     p += align256(32 * n);
   size_t cub_bytes = cub_sort_bytes(env->n);
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -296,12 +299,13 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
   StateArrays tmp;
-  tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t;
+  tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t; tmp.rtw = env->st.rtw ? rtw_t : nullptr;
   hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->st, i_out, tmp, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  if (env->st.rtw) HIP_TRY(hipMemcpyAsync(env->st.rtw, rtw_t, 32 * n, hipMemcpyDeviceToDevice, s));
   return W2A_OK;
 }
 

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   if (valid && sel && l == 0) {
     if (a.from_tuples != 2) {
       store_episode(a.st, e, make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1),
-                    make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
+                    make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget),
+                    a.tb.Wendo, a.tb.n_samples);
     }
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
 __global__ void k_init_state(StateArrays st, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n)  // sticky = -1, episode_no = -1 (first reset -> 0); finished, so a step before reset() is flagged
-    store_episode(st, (uint32_t)i, make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u));
+    store_episode(st, (uint32_t)i, make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u),
+                  nullptr, 0);
 }
 
 __global__ void k_get_state(StateArrays st, int64_t n, int32_t Y, int32_t n_samples, w2a_state_view v) {

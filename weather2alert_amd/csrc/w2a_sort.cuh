@@ -21,6 +21,10 @@ __global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArray
   dst.cold[i] = src.cold[j];
   dst.hot3[i] = src.hot3[j];
   dst.stepc[i] = src.stepc[j];
+  if (src.rtw) {
+    dst.rtw[2 * i] = src.rtw[2 * (size_t)j];
+    dst.rtw[2 * i + 1] = src.rtw[2 * (size_t)j + 1];
+  }
 }
 
 #endif  // W2A_W2A_SORT_CUH

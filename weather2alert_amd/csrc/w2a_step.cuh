@@ -84,8 +84,8 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
     // add the four run-time terms. Every lane of the group computes the same value (broadcast loads).
     const double2 lv = a.tb.L[(size_t)day_row * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y)];
-    const float4 qb = a.tb.Wendo[wrow * 2];
-    const float4 qe = a.tb.Wendo[wrow * 2 + 1];
+    const float4 qb = a.st.rtw[2 * e];      // the env's run-time-slot coefficients, copied from Wendo at reset
+    const float4 qe = a.st.rtw[2 * e + 1];
     zb = fma((double)f_lag1, (double)qb.x, lv.x);
     zb = fma((double)f_streak, (double)qb.y, zb);
     zb = fma((double)f_rem, (double)qb.z, zb);
@@ -170,7 +170,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     }
   }
   if (valid && l == 0) {
-    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2);
+    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2, a.tb.Wendo, a.tb.n_samples);
     else store_hot(a.st, e, hot2);
     a.reward[e] = r;
     a.done[e] = done ? 1 : 0;
