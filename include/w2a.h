@@ -27,9 +27,8 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 3
+#define W2A_ABI_VERSION 4
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
-#define W2A_LANES_PER_ENV 8
 
 enum {
   W2A_OK = 0,
@@ -68,7 +67,7 @@ enum { W2A_BUDGET_FIXED = 0, W2A_BUDGET_LESS_THAN = 1, W2A_BUDGET_CENTERED = 2 }
  * Replaces what HeatAlertEnv.__init__ builds (env.py:49-85): the merged (fips, year, date)
  * feature frame and the posterior coefficient tensors.
  *
- * Internal slot layout of a 32-float row (lane l of an env's 8-lane group owns slots 4l..4l+3):
+ * Internal slot layout of a 32-float row (how lanes split a row is a kernel detail, not part of the ABI):
  *   slots  0..23  table-sourced columns (reward features first, in merged-column order)
  *   slots 24..27  run-time fields: alert_lag1, alert_streak, remaining_budget, alert_2wks(agent)
  *   slot   28     25th table-sourced column if the schema has one (else 0)
@@ -108,6 +107,7 @@ typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */
 typedef struct w2a_state_view {
   int32_t *t, *used, *streak, *hist14, *last_actual, *at_budget, *budget, *n_days;
   int32_t *county_w, *year_i, *coef_col, *sample, *sticky_budget, *episode_no;
+  int32_t *finished;     /* 1 once the terminal step of the current episode has run (done was returned) */
   float *episode_return; /* running return of the current episode */
 } w2a_state_view;
 
@@ -137,9 +137,12 @@ int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, cons
  * by (seed, global env id, per-env episode number). location < 0 draws the county
  * (env.py:151-152), otherwise it is the weight-column index of the requested county.
  * budget_kw < 0 means "budget=None". Budget stickiness (env.py:167-170) is kept per env
- * unless `sticky` is 0. */
+ * unless `sticky` is 0. restart_episodes != 0: the (selected) envs' episode counters restart at 0, so a
+ * reset with an explicit seed reproduces the same episodes every time (env.py:143-145 re-creates the
+ * Generator from the seed); 0: the counters advance, which is what an autoreset does. */
 int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
-                         int sample_budget_mode, int sticky, const uint8_t *mask, float *obs, void *stream);
+                         int sample_budget_mode, int sticky, int restart_episodes, const uint8_t *mask, float *obs,
+                         void *stream);
 
 /* Parameters the same-step autoreset of w2a_step uses (same meaning as above). */
 int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,

@@ -22,7 +22,7 @@ Layout of the restatement (each function cites what it follows):
   VectorOracle           the same step arithmetic vectorised over envs (float64, same
                          summation order), used for large-N checks and the CPU baseline
   devrng_*               restatement of the build's own counter-based device RNG
-                         (weather2alert_amd/csrc/w2a_common.cuh: w2a_mix64 / draw slots);
+                         (weather2alert_amd/csrc/w2a_common.hip.h: w2a_mix64 / draw slots);
                          this part has no reference counterpart
 """
 from __future__ import annotations

@@ -223,18 +223,25 @@ def test_device_rng_reset_matches_restatement(dev):
         return int(ct.B0[cw * ct.Y + yi])
 
     sticky = np.full(n, -1)
-    for episode, (mode, mname) in enumerate([(0, None), (1, "less_than"), (2, "centered")]):
+    first = None
+    for k, (mode, mname) in enumerate([(0, None), (1, "less_than"), (2, "centered")]):
         opts = {} if mname is None else {"sample_budget": True, "sample_budget_type": mname}
         obs, _ = env.reset(seed=seed, options=opts)
-        st = {k: v.cpu().numpy() for k, v in env.state().items()}
+        st = {k_: v.cpu().numpy() for k_, v in env.state().items()}
+        # reset(seed=s) re-seeds: the episode counter restarts, so the draws are those of episode 0 every time
+        # (env.py:143-145); only the sticky budget carries over between resets (Q9)
         for i in range(0, n, 7):
-            cw, cc, yi, sm, b = O.devrng_reset_tuple(seed, gid0 + i, episode, ct.S, ct.Y, ct.n_samples,
+            cw, cc, yi, sm, b = O.devrng_reset_tuple(seed, gid0 + i, 0, ct.S, ct.Y, ct.n_samples,
                                                      ct.fips_to_weather, ct.sim_ptr, ct.sim_cnt, True, b0,
                                                      int(sticky[i]), -1, mode)
             assert (st["county_w"][i], st["coef_col"][i], st["year_i"][i], st["sample"][i], st["budget"][i]) == \
-                (cw, cc, yi, sm, b), (episode, i)
-            assert st["episode_no"][i] == episode and st["sticky_budget"][i] == b
+                (cw, cc, yi, sm, b), (k, i)
+            assert st["episode_no"][i] == 0 and st["sticky_budget"][i] == b and st["finished"][i] == 0
             sticky[i] = b
+        tup = np.stack([st[x] for x in ("county_w", "coef_col", "year_i", "sample")])
+        if first is None:
+            first = tup
+        assert np.array_equal(tup, first)  # equal seeds -> equal episodes
         assert env.check_status() == 0
         # first observation = day-0 row with zeroed history and remaining_budget = budget
         o = obs.cpu().numpy()
@@ -327,7 +334,8 @@ def test_masked_reset_leaves_lockstep_and_autoresets_in_kernel(dev):
             first.append(k)
     assert second == [52] and first == [152]
     st = env.state()
-    assert (st["episode_no"][: n // 2] == 2).all() and (st["episode_no"][n // 2:] == 1).all()
+    # the masked re-seeding reset restarted its envs' counters at 0; every env has autoreset once since
+    assert (st["episode_no"] == 1).all()
     assert (st["t"][: n // 2] == 0).all() and (st["t"][n // 2:] == 100).all()
     assert env.check_status() == 0
     env.close()
@@ -543,6 +551,34 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     env.close()
 
 
+def test_partial_rollouts_report_done_from_the_finished_bit(dev):
+    """A rollout that stops one day short leaves t = n_days-1 with the terminal step still to run: done must be
+    False and the running return must not be taken for a final one; one more day finishes every env."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=4)
+    ct = tables.compile_from_synth(sd)
+    n = 700
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    env.reset(seed=9)
+    pol = dict(kind="bernoulli", p=0.2, seed=3)
+    a = env.rollout(pol, n_steps=ct.T - 1)
+    st = env.state()
+    assert not a["done"].any() and (st["finished"] == 0).all() and (st["t"] == ct.T - 1).all()
+    b = env.rollout(pol, n_steps=1)
+    st = env.state()
+    assert b["done"].all() and (st["finished"] == 1).all() and (st["t"] == ct.T - 1).all()
+    total = a["return"].double() + b["return"].double()
+    np.testing.assert_allclose(b["final_return"].cpu().numpy(), total.cpu().numpy(), rtol=1e-5)
+    ref = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    ref.reset(seed=9)
+    whole = ref.rollout(pol)
+    assert whole["done"].all() and torch.equal(whole["alerts"], a["alerts"] + b["alerts"])
+    np.testing.assert_allclose(whole["return"].cpu().numpy(), total.cpu().numpy(), rtol=1e-5)
+    env.close()
+    ref.close()
+
+
 def test_rollout_evaluates_consecutive_episodes_in_lockstep(dev):
     from weather2alert_amd import HeatAlertVecEnv
 
@@ -608,11 +644,11 @@ def test_corrected_augmentation_and_budget(dev):
     n, gid0, seed = 600, 50, 11
     env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", env_gid0=gid0, similar_climate_counties=True,
                           fixes={"augment", "budget"})
-    for episode in range(2):
+    for seed in (11, 12):
         env.reset(seed=seed, options={"sample_budget": True})
         st = {k: v.cpu().numpy() for k, v in env.state().items()}
         for i in range(0, n, 5):
-            s = O.devrng_stream(seed, gid0 + i, episode)
+            s = O.devrng_stream(seed, gid0 + i, 0)
             c0 = O.devrng_bounded(s, O.DRAW_COUNTY, ct.S)
             li = O.devrng_bounded(s, O.DRAW_SIMILAR, int(ct.sim_cnt[c0]))
             c1 = int(ct.similar_list(c0)[li])
@@ -621,6 +657,16 @@ def test_corrected_augmentation_and_budget(dev):
             assert 0 <= st["budget"][i] <= b0  # sampled from the table budget every episode, never sticky
         assert (st["sticky_budget"] == -1).all()
     env.close()
+    # corrected augmentation with a fixed county that has no confounders row: KeyError on the host like
+    # datautils.py:123, never an out-of-range read of the similar-county list on the device
+    import copy
+    ct0 = copy.copy(ct)
+    ct0.sim_cnt = ct.sim_cnt.copy()
+    ct0.sim_cnt[3] = 0
+    e0 = HeatAlertVecEnv(16, tables=ct0, device=dev, similar_climate_counties=True, fixes={"augment"})
+    with pytest.raises(KeyError):
+        e0.reset(seed=1, options={"location": ct.fips_list[3]})
+    e0.close()
     with pytest.raises(ValueError):
         HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", fixes={"alert_2wks"})
     with pytest.raises(ValueError):

@@ -42,10 +42,37 @@ def test_replay_errors_mirror_the_reference(gold):
     ct2.n_days[:] = 0
     with pytest.raises(KeyError):
         rng.numpy_parity_episode(ct2, 0, ct.fips_list[0], False, None, None, False, "less_than")
-    ct3 = copy.copy(ct)
+    ct3 = copy.copy(ct)  # a county without a confounders row: confounders.loc[fips] (datautils.py:123)
+    ct3.__dict__.pop("_conf_groups", None)
     ct3.sim_cnt = np.zeros_like(ct.sim_cnt)
+    ct3.conf_fips, ct3.conf_group = [], []
     with pytest.raises(KeyError):
         rng.numpy_parity_episode(ct3, 0, ct.fips_list[0], True, None, None, False, "less_than")
+
+
+def test_augmentation_of_a_county_outside_fips_list():
+    """env.py:115-127 with similar_climate_counties=True never looks the requested county up in fips_list: a county
+    that only has weather and a confounders row still resets (coefficients of a drawn similar county, its own
+    weather), while without augmentation list.index raises ValueError (env.py:121). Checked against the oracle's
+    restatement of the same draws."""
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd import synth
+
+    sd = synth.make_synth("linear", n_fips=30, years=[2006, 2007, 2008], n_samples=7, seed=4, extra_confounder_fips=6)
+    outsider = next(f for f in sd.confounder_fips if f not in sd.fips_list)
+    sd.fips_weather[5] = outsider  # that county's state tables now belong to a county outside fips_list
+    ct = tables.compile_from_synth(sd)
+    rd = O.RefData.from_synth(sd)
+    assert outsider not in ct.fips_list and ct.fips_weather[5] == outsider
+    for seed in range(12):
+        w, y_i, li, ci, b, info = rng.numpy_parity_episode(ct, seed, outsider, True, None, None, seed % 2 == 1,
+                                                            "centered")
+        loc_o, li_o, year_o, ci_o, b_o, info_o = O.numpy_parity_reset_tuple(rd, seed, outsider, True, None, None,
+                                                                           seed % 2 == 1, "centered")
+        assert (ct.fips_weather[w], ct.years[y_i], li, ci, b, info) == (loc_o, year_o, li_o, ci_o, b_o, info_o)
+        assert w == 5 and info in ct.fips_list
+    with pytest.raises(ValueError):
+        rng.numpy_parity_episode(ct, 0, outsider, False, None, None, False, "less_than")
 
 
 def test_corrected_augmentation_uses_the_drawn_county(gold):

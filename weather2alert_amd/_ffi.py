@@ -7,13 +7,12 @@ import os
 from . import build as _build
 
 ROW_FLOATS = 32
-LANES_PER_ENV = 8
 
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -47,7 +46,7 @@ class Tables(C.Structure):
 
 
 STATE_FIELDS = ["t", "used", "streak", "hist14", "last_actual", "at_budget", "budget", "n_days", "county_w",
-                "year_i", "coef_col", "sample", "sticky_budget", "episode_no", "episode_return"]
+                "year_i", "coef_col", "sample", "sticky_budget", "episode_no", "finished", "episode_return"]
 
 
 class StateView(C.Structure):
@@ -94,7 +93,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_reset.restype = C.c_int
     lib.w2a_reset.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.w2a_reset_device_rng.restype = C.c_int
-    lib.w2a_reset_device_rng.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int, vp, vp, vp]
+    lib.w2a_reset_device_rng.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.w2a_set_autoreset.restype = C.c_int
     lib.w2a_set_autoreset.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int]
     lib.w2a_step.restype = C.c_int

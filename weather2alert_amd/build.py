@@ -30,7 +30,7 @@ def needs_build() -> bool:
         return True
     m = os.path.getmtime(LIB)
     csrc = os.path.dirname(SRC)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cuh"))] + [os.path.join(INC, "w2a.h")]
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hip.h"))] + [os.path.join(INC, "w2a.h")]
     return any(os.path.getmtime(d) > m for d in deps)
 
 

@@ -1,7 +1,7 @@
-// w2a_common.cuh -- geometry, packed per-env state, device RNG, DPP reductions, episode draw, observation tile
+// w2a_common.hip.h -- geometry, packed per-env state, device RNG, DPP reductions, episode draw, observation tile
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_COMMON_CUH
-#define W2A_W2A_COMMON_CUH
+#ifndef W2A_COMMON_HIP_H
+#define W2A_COMMON_HIP_H
 
 #ifndef LANES
 #define LANES 4  // lanes per env: 8, 4, 2 or 1 (A/B-tested on MI355X)
@@ -193,7 +193,7 @@ __device__ __forceinline__ uint32_t rng_bounded(uint64_t stream, uint32_t slot, 
 }
 
 // ----------------------------------------------------------------------------------------
-// cross-lane helpers (8-lane groups inside a DPP row of 16)
+// cross-lane helpers (LANES-lane groups inside a DPP row of 16)
 // ----------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-// all-reduce (sum) over the 8 lanes of a group; every lane ends with the total
+// all-reduce (sum) over the LANES lanes of a group; every lane ends with the total
 __device__ __forceinline__ double group_sum(double v) {
   if (LANES >= 2) v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
   if (LANES >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
@@ -256,8 +256,11 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
     if (ns <= 0) { bad = 1; ns = 1; }
     coef_col = rng_bounded(st, 1, (uint32_t)ns);  // position inside the filtered list
     if ((tb.fixes & W2A_FIX_AUGMENT) && tb.sim_idx) {
-      // corrected augmentation: the drawn similar county supplies both the weather and the coefficients
-      county = (uint32_t)tb.sim_idx[tb.sim_ptr[county] + (int32_t)coef_col];
+      // corrected augmentation: the drawn similar county supplies both the weather and the coefficients.
+      // An empty list (county absent from the confounders: the reference raises KeyError, datautils.py:123)
+      // is never indexed; the looked-up county is range-checked before it indexes any table.
+      if (!bad) county = (uint32_t)tb.sim_idx[tb.sim_ptr[county] + (int32_t)coef_col];
+      if (county >= (uint32_t)tb.S) { county = 0; bad = 1; }
       coef_col = county;
     }
   }
@@ -364,4 +367,4 @@ __device__ __forceinline__ void store_obs_tile(void *__restrict__ obs_any, float
   __builtin_amdgcn_wave_barrier();
 }
 
-#endif  // W2A_W2A_COMMON_CUH
+#endif  // W2A_COMMON_HIP_H

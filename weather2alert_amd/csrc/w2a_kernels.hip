@@ -33,12 +33,12 @@
 
 #include "w2a.h"
 
-#include "w2a_common.cuh"
-#include "w2a_step.cuh"
-#include "w2a_reset.cuh"
-#include "w2a_logit_table.cuh"
-#include "w2a_rollout.cuh"
-#include "w2a_sort.cuh"
+#include "w2a_common.hip.h"
+#include "w2a_step.hip.h"
+#include "w2a_reset.hip.h"
+#include "w2a_logit_table.hip.h"
+#include "w2a_rollout.hip.h"
+#include "w2a_sort.hip.h"
 
 // ----------------------------------------------------------------------------------------
 // C ABI
@@ -168,13 +168,14 @@ static int fill_cfg(const w2a_env *env, ResetCfg &rc, uint64_t seed, int32_t loc
 }
 
 int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
-                         int sample_budget_mode, int sticky, const uint8_t *mask, float *obs, void *stream) {
+                         int sample_budget_mode, int sticky, int restart_episodes, const uint8_t *mask, float *obs,
+                         void *stream) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_reset_device_rng: NULL handle");
   ResetArgs a;
   memset(&a, 0, sizeof(a));
   int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
-  a.mask = mask; a.obs = obs; a.from_tuples = 0;
+  a.mask = mask; a.obs = obs; a.from_tuples = 0; a.restart = restart_episodes ? 1 : 0;
   return launch_reset(env, a, stream);
 }
 

@@ -1,7 +1,7 @@
-// w2a_logit_table.cuh -- k_logit_table: grouped fp64-MFMA reward precompute; k_pack_wendo
+// w2a_logit_table.hip.h -- k_logit_table: grouped fp64-MFMA reward precompute; k_pack_wendo
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_LOGIT_TABLE_CUH
-#define W2A_W2A_LOGIT_TABLE_CUH
+#ifndef W2A_LOGIT_TABLE_HIP_H
+#define W2A_LOGIT_TABLE_HIP_H
 
 // ----------------------------------------------------------------------------------------
 // logit-table precompute ("dense reward GEMM", BASELINE configs[3]/[4])
@@ -138,4 +138,4 @@ __global__ void k_pack_wendo(const float4 *W, float4 *Wendo, int64_t rows) {
   }
 }
 
-#endif  // W2A_W2A_LOGIT_TABLE_CUH
+#endif  // W2A_LOGIT_TABLE_HIP_H

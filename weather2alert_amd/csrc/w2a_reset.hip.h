@@ -1,10 +1,10 @@
-// w2a_reset.cuh -- k_reset / k_init_state / k_get_state (env.py:133-184, 228-236)
+// w2a_reset.hip.h -- k_reset / k_init_state / k_get_state (env.py:133-184, 228-236)
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_RESET_CUH
-#define W2A_W2A_RESET_CUH
+#ifndef W2A_RESET_HIP_H
+#define W2A_RESET_HIP_H
 
 // ----------------------------------------------------------------------------------------
-// reset kernels (same 8-lane geometry so the observation tile code is shared)
+// reset kernels (same lane-group geometry as k_step so the observation tile code is shared)
 // ----------------------------------------------------------------------------------------
 struct ResetArgs {
   DevTables tb;
@@ -19,6 +19,7 @@ struct ResetArgs {
   int64_t gid0;
   ResetCfg rc;
   int32_t from_tuples;  // 0: device RNG draw, 1: caller's tuples, 2: observe only (state untouched)
+  int32_t restart;      // device RNG draw: 1 = the per-env episode counter restarts at 0 (explicit re-seed)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
@@ -61,6 +62,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     ep.budget = a.budget ? a.budget[e] : a.tb.B0[ep.ep_row];
     ep.sticky = (int32_t)cold.z;
   } else {
+    // an explicit re-seed restarts the per-env episode counter, so equal seeds give equal episodes
+    // (env.py:143-145 re-creates the Generator); autoresets keep counting up from there
+    if (a.restart) cold.w = 0xFFFFFFFFu;
     ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
     bad = ep.bad;
   }
@@ -115,6 +119,7 @@ __global__ void k_get_state(StateArrays st, int64_t n, int32_t Y, int32_t n_samp
   if (v.sample) v.sample[i] = (int32_t)W_SAMPLE(c.y);
   if (v.sticky_budget) v.sticky_budget[i] = (int32_t)c.z;
   if (v.episode_no) v.episode_no[i] = (int32_t)c.w;
+  if (v.finished) v.finished[i] = (int32_t)D1_FIN(h.y);
 }
 
-#endif  // W2A_W2A_RESET_CUH
+#endif  // W2A_RESET_HIP_H

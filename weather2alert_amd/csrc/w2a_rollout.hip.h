@@ -1,7 +1,7 @@
-// w2a_rollout.cuh -- k_rollout: on-device policy rollout
+// w2a_rollout.hip.h -- k_rollout: on-device policy rollout
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_ROLLOUT_CUH
-#define W2A_W2A_ROLLOUT_CUH
+#ifndef W2A_ROLLOUT_HIP_H
+#define W2A_ROLLOUT_HIP_H
 
 // ----------------------------------------------------------------------------------------
 // on-device policy rollout: many days per launch, coefficients kept in registers
@@ -154,4 +154,4 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   }
 }
 
-#endif  // W2A_W2A_ROLLOUT_CUH
+#endif  // W2A_ROLLOUT_HIP_H

@@ -1,7 +1,7 @@
-// w2a_sort.cuh -- relabelling sort for episode_order="sorted"
+// w2a_sort.hip.h -- relabelling sort for episode_order="sorted"
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_SORT_CUH
-#define W2A_W2A_SORT_CUH
+#ifndef W2A_SORT_HIP_H
+#define W2A_SORT_HIP_H
 
 // ----------------------------------------------------------------------------------------
 // episode_order="sorted": relabel envs so that neighbours share coefficient / logit rows
@@ -27,4 +27,4 @@ __global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArray
   }
 }
 
-#endif  // W2A_W2A_SORT_CUH
+#endif  // W2A_SORT_HIP_H

@@ -1,7 +1,7 @@
-// w2a_step.cuh -- k_step: one day for every env (env.py:238-262)
+// w2a_step.hip.h -- k_step: one day for every env (env.py:238-262)
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
-#ifndef W2A_W2A_STEP_CUH
-#define W2A_W2A_STEP_CUH
+#ifndef W2A_STEP_HIP_H
+#define W2A_STEP_HIP_H
 
 // ----------------------------------------------------------------------------------------
 // step kernel
@@ -209,4 +209,4 @@ __global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) vo
   step_tile<AUTORESET, WRITE_OBS, TABLE, FIXES>(a, s_tile[wave], wave_env0, lane, l, grp, valid, e, cold, hot, act);
 }
 
-#endif  // W2A_W2A_STEP_CUH
+#endif  // W2A_STEP_HIP_H

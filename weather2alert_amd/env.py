@@ -2,7 +2,7 @@
 
 ``HeatAlertVecEnv`` steps ``num_envs`` independent copies of the reference's
 ``weather2alert.env.HeatAlertEnv`` (``/root/reference/src/weather2alert/env.py``) inside
-hand-written gfx950 kernels (``csrc/*.cuh``, ``csrc/w2a_kernels.hip`` through the C ABI of
+hand-written gfx950 kernels (``csrc/*.hip.h``, ``csrc/w2a_kernels.hip`` through the C ABI of
 ``include/w2a.h``). ``HeatAlertEnv`` is the ``num_envs=1`` drop-in with the reference's
 exact constructor / ``reset`` / ``step`` signatures and NumPy-seed parity.
 
@@ -12,6 +12,7 @@ fallback -- constructing an env without a ROCm device or without libw2a.so raise
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Mapping, Sequence
 from typing import Literal
 
 import numpy as np
@@ -27,8 +28,13 @@ _ACT_CODES = {torch.int32: _ffi.ACT_I32, torch.int64: _ffi.ACT_I64, torch.uint8:
 _BUDGET_MODES = {"less_than": _ffi.BUDGET_LESS_THAN, "centered": _ffi.BUDGET_CENTERED}
 _cur_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
+try:  # a real Gymnasium VectorEnv when the package is importable; the same duck-typed surface otherwise
+    from gymnasium.vector import VectorEnv as _VectorEnvBase
+except ImportError:  # gymnasium is not a dependency of the reference's numerical path
+    _VectorEnvBase = object
 
-class HeatAlertVecEnv:
+
+class HeatAlertVecEnv(_VectorEnvBase):
     """``num_envs`` heat-alert environments stepped in lock step on one MI355X.
 
     Constructor keeps the reference's keyword arguments (env.py:20-29) and adds:
@@ -73,6 +79,9 @@ class HeatAlertVecEnv:
     """
 
     metadata = {"autoreset_mode": "same_step"}
+    spec = None
+    render_mode = None
+    closed = False
 
     def __init__(
         self,
@@ -207,6 +216,32 @@ class HeatAlertVecEnv:
         self._sticky = [budget] * n  # host mirror of self.budget per env (numpy_parity mode, Q9)
         self._needs_reset = True
         self._last_opts: dict = {}
+        self._np_random = None
+        self._np_random_seed = None
+
+    # ------------------------------------------------------------------ Gymnasium VectorEnv attributes
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def np_random(self) -> np.random.Generator:
+        """Host Generator seeded by the last explicit reset(seed=...) (Gymnasium convention). Episode draws come
+        from the device RNG (seed_mode="device") or from per-env Generators (seed_mode="numpy_parity"), not from
+        this one; it serves wrappers and samplers that expect the attribute."""
+        if self._np_random is None:
+            self._np_random_seed = int(np.random.SeedSequence().entropy % (2**63))
+            self._np_random = np.random.default_rng(self._np_random_seed)
+        return self._np_random
+
+    @np_random.setter
+    def np_random(self, value: np.random.Generator):
+        self._np_random, self._np_random_seed = value, -1
+
+    @property
+    def np_random_seed(self):
+        self.np_random  # noqa: B018  (initialises on first use)
+        return self._np_random_seed
 
     # ------------------------------------------------------------------ plumbing
     def _set_step_mode(self):
@@ -222,11 +257,12 @@ class HeatAlertVecEnv:
             return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def close(self):
+    def close(self, **kwargs):
         if getattr(self, "_h", None):
             torch.cuda.synchronize(self.device)
             self._lib.w2a_destroy(self._h)
             self._h = None
+        self.closed = True
 
     def __del__(self):  # pragma: no cover
         try:
@@ -313,6 +349,8 @@ class HeatAlertVecEnv:
         "episodes": dict of int arrays (county_w, year_i, coef_col, sample, budget) to inject
         episode tuples directly, and "mask": bool[num_envs] to reset a subset."""
         options = dict(options or {})
+        if seed is not None and not isinstance(seed, (list, tuple, np.ndarray)):
+            self._np_random, self._np_random_seed = np.random.default_rng(int(seed)), int(seed)
         mask = options.get("mask")
         mask_t = None
         if mask is not None:
@@ -414,6 +452,8 @@ class HeatAlertVecEnv:
         aug = bool(self._opt(options, "similar_climate_counties", self.similar_climate_counties))
         if aug and self.reward_path == "table":
             raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
+        if aug and loc_i >= 0 and self.ct.sim_cnt[loc_i] <= 0:
+            raise KeyError(loc)  # county absent from the confounders: confounders.loc[fips] (datautils.py:123)
         bk = self._ctor_budget if self._ctor_budget is not None else options.get("budget")
         mode = _ffi.BUDGET_FIXED
         if self._opt(options, "sample_budget", False):
@@ -436,18 +476,21 @@ class HeatAlertVecEnv:
         if self.episode_order == "sorted" and mask_t is not None:
             raise ValueError("episode_order='sorted' resets the whole batch; masks are not supported")
         self._reset_cfg = cfg
-        self._launch_device_reset(mask_t, obs_ptr)
+        # reset() re-seeds (explicit seed, or a fresh one for seed=None like env.py:143-145), so the per-env episode
+        # counters restart: equal seeds give equal episodes. Autoresets advance the counters instead.
+        self._launch_device_reset(mask_t, obs_ptr, restart=True)
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.w2a_set_autoreset(self._h, *cfg), "w2a_set_autoreset")
         self._keep = (mask_t,)
 
-    def _launch_device_reset(self, mask_t, obs_ptr):
-        """Device-RNG reset of the batch (next episode number per env); in sorted mode followed by the
-        relabelling sort and the observation pass. Asynchronous, no host sync."""
+    def _launch_device_reset(self, mask_t, obs_ptr, restart=False):
+        """Device-RNG reset of the batch (restart: episode number 0 for a re-seeding reset(); else the next episode
+        number per env, i.e. an autoreset); in sorted mode followed by the relabelling sort and the observation
+        pass. Asynchronous, no host sync."""
         lib, st = self._lib, self._stream()
         srt = self.episode_order == "sorted"
         with torch.cuda.device(self.device):
-            _ffi.check(lib.w2a_reset_device_rng(self._h, *self._reset_cfg, None if mask_t is None else
+            _ffi.check(lib.w2a_reset_device_rng(self._h, *self._reset_cfg, int(restart), None if mask_t is None else
                                                 mask_t.data_ptr(), None if srt else obs_ptr, st),
                        "w2a_reset_device_rng")
             if srt:
@@ -538,7 +581,7 @@ class HeatAlertVecEnv:
                                              self._stream()), "w2a_rollout")
         self._keep_pol = keep
         st = self.state()
-        out["done"] = st["t"] + 1 >= st["n_days"]
+        out["done"] = st["finished"].bool()  # the terminal step has run (t stops at n_days-1 before AND after it)
         out["final_return"] = self._final_return.clone()
         if mask is not None:
             bits = torch.arange(32, device=dev, dtype=torch.int32)
@@ -593,70 +636,98 @@ class HeatAlertVecEnv:
         return _LazyInfo(self)
 
 
-class _LazyInfo(dict):
-    """info dict whose entries are fetched from the device on first access (env.py:228-236).
-    Device tensors: remaining_budget, at_budget, location_index (coefficient column), county_w, year,
-    final_return, t; host values: feature_names, and the reference's string entries episode_index
-    ("<fips>_<year>") and location (env.py:118: under augmentation the fips at the drawn position of the
-    filtered similar-county list) as lists, built only when asked for."""
+class _LazyStrings(Sequence):
+    """The reference's per-env string entries of info (env.py:229-236) built on demand: element i is formatted
+    when it is asked for, so iterating over an info mapping of a million envs does not build a million strings."""
+
+    def __init__(self, n: int, fn):
+        self._n, self._fn = int(n), fn
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._fn(j) for j in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._fn(i)
+
+    def __eq__(self, other):
+        try:
+            return len(other) == self._n and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        head = ", ".join(repr(self[i]) for i in range(min(self._n, 3)))
+        return f"<{self._n} strings: {head}{', ...' if self._n > 3 else ''}>"
+
+
+class _LazyInfo(Mapping):
+    """info mapping whose entries are fetched from the device on first access (env.py:228-236); it shows the env's
+    state at that moment. Device tensors: remaining_budget, at_budget, location_index (coefficient column),
+    county_w, year, final_return, t; host values: feature_names, and the reference's string entries episode_index
+    ("<fips>_<year>") and location (env.py:118: under augmentation the fips at the drawn position of the filtered
+    similar-county list) as lazy sequences of num_envs strings. A real Mapping: get(), values(), items(), `in`
+    and len() all agree with iteration."""
 
     _KEYS = ("remaining_budget", "at_budget", "location_index", "county_w", "year", "feature_names",
              "final_return", "t", "episode_index", "location")
     _HOST_KEYS = ("episode_index", "location")
 
     def __init__(self, env: HeatAlertVecEnv):
-        super().__init__()
         self._env = env
+        self._d: dict = {}
+        self._np: dict = {}
 
     def _fill(self):
-        if not super().__len__():
+        if not self._d:
             e = self._env
             st = e.state()
             years = torch.as_tensor(e.ct.years, dtype=torch.int32, device=e.device)
-            super().update(
+            self._d.update(
                 remaining_budget=st["budget"] - st["used"], at_budget=st["at_budget"].bool(),
                 location_index=st["coef_col"], county_w=st["county_w"], year=years[st["year_i"].long()],
                 feature_names=e.feature_names, final_return=e._final_return, t=st["t"])
 
+    def _host_arr(self, k):
+        if k not in self._np:
+            self._np[k] = self._d[k].cpu().numpy()
+        return self._np[k]
+
     def _host(self, k):
-        e, ct = self._env, self._env.ct
-        cw = super().__getitem__("county_w").cpu().numpy()
+        e, ct, n = self._env, self._env.ct, self._env.num_envs
         if k == "episode_index":
-            yr = super().__getitem__("year").cpu().numpy()
-            return [f"{ct.fips_weather[c]}_{y}" for c, y in zip(cw, yr)]
+            return _LazyStrings(n, lambda i: f"{ct.fips_weather[self._host_arr('county_w')[i]]}_"
+                                             f"{self._host_arr('year')[i]}")
         if e.seed_mode == "numpy_parity" and getattr(e, "_info_location", None):
-            return list(e._info_location)
-        col = super().__getitem__("location_index").cpu().numpy()
+            loc = list(e._info_location)
+            return _LazyStrings(n, lambda i: loc[i])
         # device-RNG episodes: whether the last reset augmented is a property of the reset call
         aug = bool(e._reset_cfg[2]) if e._reset_cfg is not None else False
         if not aug or "augment" in e.fixes:
-            return [ct.fips_list[li] for li in col]
-        out = []
-        for c, li in zip(cw, col):  # position li of the filtered similar list of the requested county (Q8)
-            sl = ct.similar_list(ct.fips_index(ct.fips_weather[c]))
-            out.append(ct.fips_list[int(sl[li])])
-        return out
+            return _LazyStrings(n, lambda i: ct.fips_list[self._host_arr("location_index")[i]])
+
+        def drawn(i):  # position li of the filtered similar list of the requested county (Q8)
+            sl = ct.similar_list(ct.fips_index(ct.fips_weather[self._host_arr("county_w")[i]]))
+            return ct.fips_list[int(sl[self._host_arr("location_index")[i]])]
+
+        return _LazyStrings(n, drawn)
 
     def __getitem__(self, k):
+        if k not in self._KEYS:
+            raise KeyError(k)
         self._fill()
-        if k in self._HOST_KEYS and not super().__contains__(k):
-            super().__setitem__(k, self._host(k))
-        return super().__getitem__(k)
-
-    def __contains__(self, k):
-        return k in self._KEYS
-
-    def keys(self):
-        self._fill()
-        return super().keys()
-
-    def items(self):
-        self._fill()
-        return super().items()
+        if k in self._HOST_KEYS and k not in self._d:
+            self._d[k] = self._host(k)
+        return self._d[k]
 
     def __iter__(self):
-        self._fill()
-        return super().__iter__()
+        return iter(self._KEYS)
 
     def __len__(self):
         return len(self._KEYS)

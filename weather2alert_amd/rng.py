@@ -19,27 +19,31 @@ def numpy_parity_episode(ct: CompiledTables, seed: int, location: str | None, au
 
     Draw order (SURVEY §3.2): choice(fips_list) if location is None; choice(range(n_similar)) if augment;
     choice(valid_years); integers(0, n_samples); budget integers if sample_budget. Raises what the reference
-    raises: ValueError for a location outside fips_list (env.py:121), KeyError for a county absent from the
-    confounders (datautils.py:123) or a (county, year) without data (env.py:127)."""
+    raises: ValueError for a location outside fips_list without augmentation (env.py:121), KeyError for a
+    county absent from the confounders (datautils.py:123) or a (county, year) without data (env.py:127)."""
     rng = np.random.default_rng(seed)
     if location is None:
         location = str(rng.choice(ct.fips_list))  # env.py:151-152
-    county = ct.fips_index(location)  # env.py:121 list.index -> ValueError
     info_location = location
     if augment:
-        ns = int(ct.sim_cnt[county])
-        if ns == 0:
-            raise KeyError(location)  # confounders.loc[fips] (datautils.py:123)
-        li = int(rng.choice(range(ns)))  # env.py:117: index into the FILTERED list (Q8)
-        drawn = int(ct.similar_list(county)[li])
+        # env.py:115-118: the requested county is looked up in the confounders only (KeyError, datautils.py:123),
+        # never in fips_list -- a county outside fips_list still augments
+        sim = ct.similar_for_fips(location)
+        if len(sim) == 0:
+            raise ValueError("a must be a positive integer unless no samples are taken")  # rng.choice(range(0))
+        li = int(rng.choice(range(len(sim))))  # env.py:117: index into the FILTERED list (Q8)
+        drawn = int(sim[li])
         info_location = ct.fips_list[drawn]  # env.py:118
         if fix_augment:  # corrected Q8: the drawn county supplies weather and coefficients
-            county = li = drawn
+            li = drawn
             location = info_location
     else:
-        li = county
+        li = ct.fips_index(location)  # env.py:121 list.index -> ValueError
     year = int(rng.choice(ct.years))  # env.py:125
-    w = int(ct.fips_to_weather[county])
+    wpos = ct.__dict__.get("_weather_pos")
+    if wpos is None:
+        wpos = ct.__dict__["_weather_pos"] = {f: i for i, f in enumerate(ct.fips_weather)}
+    w = wpos.get(location, -1)  # merged.loc[(location, year)] (env.py:127): the REQUESTED county's weather
     y_i = ct.years.index(year)
     if w < 0 or ct.n_days[w * ct.Y + y_i] <= 0:
         raise KeyError((location, year))  # env.py:127

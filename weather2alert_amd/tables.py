@@ -78,6 +78,8 @@ class CompiledTables:
     effectiveness_keys: list[str]
     sig_categories: list[str] = field(default_factory=list)
     f32_exact: bool = True  # every table value was exactly representable in float32
+    conf_fips: list[str] = field(default_factory=list)   # confounders rows (file order) and their climate group
+    conf_group: list[str] = field(default_factory=list)  # (datautils.py:109-120), for counties outside fips_list
 
     @property
     def feature_names(self) -> list[str]:
@@ -112,6 +114,26 @@ class CompiledTables:
     def similar_list(self, county: int) -> np.ndarray:
         return self.sim_idx[self.sim_ptr[county]: self.sim_ptr[county + 1]]
 
+    def similar_for_fips(self, fips: str) -> np.ndarray:
+        """fips_list indices of get_similar_counties(fips) ∩ fips_list in confounders order for ANY county of the
+        confounders table, inside fips_list or not (env.py:115-116 never looks the requested county up in
+        fips_list). KeyError when the county has no confounders row (datautils.py:123)."""
+        pos = self.__dict__.get("_fips_pos") or {f: i for i, f in enumerate(self.fips_list)}
+        if fips in pos and self.sim_cnt[pos[fips]] > 0:
+            return self.similar_list(pos[fips])
+        groups = self.__dict__.get("_conf_groups")
+        if groups is None:
+            first, members = {}, {}
+            for f, g in zip(self.conf_fips, self.conf_group):
+                first.setdefault(f, g)
+                if f in pos:
+                    members.setdefault(g, []).append(pos[f])
+            groups = self.__dict__["_conf_groups"] = (first, {g: np.asarray(v, np.int32) for g, v in members.items()})
+        first, members = groups
+        if fips not in first:
+            raise KeyError(fips)
+        return members.get(first[fips], np.zeros(0, np.int32))
+
     def nbytes(self) -> int:
         return int(self.X.nbytes + self.W.nbytes + self.n_days.nbytes + self.B0.nbytes)
 
@@ -123,7 +145,7 @@ class CompiledTables:
 
         meta = {k: getattr(self, k) for k in ("columns", "fips_weather", "years", "T", "fips_list", "n_samples",
                                               "obs_slot", "slot_of", "baseline_keys", "effectiveness_keys",
-                                              "sig_categories", "f32_exact")}
+                                              "sig_categories", "f32_exact", "conf_fips", "conf_group")}
         np.savez_compressed(path, meta_json=np.asarray(json.dumps(meta)),
                             **{k: getattr(self, k) for k in self._ARRAYS})
 
@@ -212,7 +234,8 @@ def _finish(columns, fips_weather, years, T, X, n_days, B0, post, fips_list, con
         X=X, n_days=n_days.astype(np.int32), B0=B0.astype(np.int32), W=W, fips_list=list(fips_list),
         n_samples=n_samples, fips_to_weather=f2w, sim_cnt=cnt, sim_ptr=ptr, sim_idx=idx, obs_slot=obs_slot,
         slot_of=slot_of, baseline_keys=b_keys, effectiveness_keys=e_keys, sig_categories=list(sig_categories),
-        f32_exact=bool(f32_exact))
+        f32_exact=bool(f32_exact), conf_fips=[str(f) for f in conf_fips],
+        conf_group=[climate_group(str(f), str(z)) for f, z in zip(conf_fips, conf_zone)])
 
 
 def compile_from_files(data_dir: str | None, weights: str = "nn_full_medicare_all", split: str = "65k",
