@@ -9,8 +9,18 @@ including the same-step autoreset when an episode ends (every 153 steps, lock st
 N>1 GPUs, the RCCL all-gather of the finished episodes' returns. Inputs (tables, state, a
 pool of action tensors) are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0). `roofline` prices the step kernel against HBM with SURVEY §8d's
-algorithmic bytes (489 B per env-step); `cpu_baseline` times the NumPy oracle on the host.
+`--gpus N` with N > 1 launches itself: when no launcher has set WORLD_SIZE, this process -- before it
+imports torch or touches a GPU -- starts N children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set), waits for them and forwards rank 0's JSON line. Under torchrun (WORLD_SIZE set) it is
+simply one of the ranks.
+
+Prints ONE JSON line (rank 0). `roofline` prices the step kernel against HBM with the COMPULSORY bytes
+of the variant that ran (what must cross HBM per env-step however good the caches are: actions and
+per-env state in, reward / done / observation / state out -- 161 B with observations, 45 B without);
+tables are not charged because every env of a lock-step batch shares one 1 MB day slice and the 19 MB
+coefficient table lives in L2 / Infinity Cache. `roofline.traffic` is the fabric traffic the PMC counters
+saw for the same kernel sources (profiles/traffic_latest.json, refused when the sources differ);
+`cpu_baseline` times the NumPy oracle on the host.
 """
 from __future__ import annotations
 
@@ -24,37 +34,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 489  # action 4 + state 20r + row 100 + weights 224 + reward 4 + done 1 + obs 116 + state 20w
-ALGO_BYTES_NO_OBS = 373
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+SURVEY_8D_BYTES = {"obs": 489, "no_obs": 373}  # SURVEY §8d's model (charges table rows to HBM): reported beside
 
 WORKLOADS = {
-    # name: (weights list, num_envs per GPU, similar_climate_counties, reward_path, description)
-    "configs1": ("linear", 65536, False, "gather",
+    # name: (weights list, num_envs per GPU, similar_climate_counties, description)
+    "configs1": ("linear", 65536, False,
                  "configs[1]: 65,536 envs, weights/linear (S=746), random county per env"),
-    "configs2": ("linear", 1048576, True, "gather",
+    "configs2": ("linear", 1048576, True,
                  "configs[2]: 1,048,576 envs, weights/linear (S=746), similar_climate_counties=True"),
-    "configs3": ("nn_full_medicare_all", 1048576, False, "table",
-                 "configs[3]: 1,048,576 envs, nn_full_medicare_all shape (S=720), logit table from the grouped "
-                 "fp64-MFMA GEMM"),
-    "configs3_gather": ("nn_full_medicare_all", 1048576, False, "gather",
-                        "configs[3] shape on the row-gather kernel (A/B for the table path)"),
-    "configs1_table": ("linear", 65536, False, "table", "configs[1] shape on the logit-table path"),
+    "configs3": ("nn_full_medicare_all", 1048576, False,
+                 "configs[3]: 1,048,576 envs, nn_full_medicare_all shape (S=720), random county per env"),
+    "configs4": ("nn_full_medicare_all", 1048576, False,
+                 "configs[4]: 1,048,576 envs per GPU, nn_full_medicare_all shape (S=720), RCCL all-gather of the "
+                 "episodic returns once per episode"),
+    "launcher_stub": (None, 4096, False,
+                      "launcher / collective rehearsal without env stepping (no GPU needed; not a measurement)"),
 }
-ALGO_BYTES_TABLE = 305  # SURVEY §8d logit-table path
 
 
-def parse():
+def compulsory_bytes(n_obs: int, write_obs: bool) -> dict:
+    """Bytes per env-step that must cross HBM for the row-gather step kernel."""
+    rd = {"action": 4, "hot3": 12, "stepc": 12}
+    wr = {"reward": 4, "done": 1, "hot3": 12}
+    if write_obs:
+        wr["obs"] = 4 * n_obs
+    return {"read": rd, "write": wr, "total": sum(rd.values()) + sum(wr.values())}
+
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1530, help="timed steps (default: 10 episodes, SURVEY §8d)")
     p.add_argument("--warmup", type=int, default=153, help="untimed steps (default: 1 episode)")
-    p.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS))
+    p.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                   help="default: configs2 on one GPU (the config the >= 10 M target is quoted on), configs4 on several")
     p.add_argument("--num-envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
-    p.add_argument("--obs-f16", action="store_true", help="opt-in half-precision observations (58 instead of 116 B/env)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the reported extras (sorted episode order)")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the reported extras (always-alert policy, sorted episode order, posterior-mean reward)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: the workload's env count per GPU (default); strong: that count split over the GPUs")
@@ -63,11 +82,54 @@ def parse():
                         "small batches); the timed region still runs exactly --steps steps")
     p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
                    help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
+    p.add_argument("--step-kernel", default="auto", choices=["auto", "classic"])
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                   help="gloo = rehearsal of the multi-rank path with several ranks sharing one GPU")
-    return p.parse_args()
+                   help="gloo = rehearsal of the multi-rank path (ranks share the GPUs there are; with the "
+                        "launcher_stub workload it needs no GPU at all)")
+    a = p.parse_args(argv)
+    if a.workload is None:
+        a.workload = "configs2" if a.gpus == 1 else "configs4"
+    return a
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """`--gpus N` without a launcher: one child per GPU. This process has not imported torch and never touches a
+    GPU; children are fresh interpreters (fork + exec of python), each of which initialises its own device."""
+    import subprocess
+
+    n = args.gpus
+    port = _free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(args):
     """One host process of the multi-core CPU baseline: builds its own tables (spawned, no GPU), steps the
     NumPy vector oracle on its share of the envs and returns (env_steps, seconds spent stepping)."""
@@ -161,31 +223,95 @@ def cpu_baseline(sd, ct, seed=0):
     }
 
 
+# ------------------------------------------------------------------------------------------ stub workload
+def run_stub(args, rank, world):
+    """Launcher / collective rehearsal: everything bench.py does around the env (process group, barrier,
+    per-episode return all-gather, max-over-ranks timing, one JSON line from rank 0) with a stand-in for the
+    env's returns. Runs on CPU with --backend gloo; it measures nothing about the kernels."""
+    import torch
+
+    from weather2alert_amd import dist as wdist
+
+    use_gpu = args.backend == "nccl"
+    device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}") if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    wdist.init_from_env(args.backend, device if use_gpu else None)
+    n = args.num_envs or WORKLOADS["launcher_stub"][1]
+    gather = wdist.ReturnGatherer(n, device)
+    gid0 = rank * n
+    returns = -(torch.arange(gid0, gid0 + n, dtype=torch.float32, device=device) % 97)
+    T, coll = 153, []
+    wdist.barrier()
+    t0 = time.perf_counter()
+    for s in range(1, args.steps + 1):
+        if s % T == 0:
+            c0 = time.perf_counter()
+            gather.gather(returns)
+            coll.append(time.perf_counter() - c0)
+    wdist.barrier()
+    wall = wdist.max_over_ranks(time.perf_counter() - t0, device)
+    allr = gather.gather(returns)
+    expect = -(torch.arange(0, n * world, dtype=torch.float32, device=device) % 97)
+    ok = bool(torch.equal(allr, expect))
+    import torch.distributed as td
+
+    seen = td.get_world_size() if td.is_initialized() else 1
+    if rank == 0:
+        print(json.dumps({
+            "metric": "env_steps_per_sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / max(args.steps, 1), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "n/a", "data": "stub",
+            "config": {"workload": WORKLOADS["launcher_stub"][3], "num_envs_per_gpu": n, "backend": args.backend},
+            "rccl_ranks_seen": seen, "collective_ms": (sum(coll) / len(coll) * 1e3) if coll else None,
+            "gather_ok": ok, "stub": True}), flush=True)
+    wdist.barrier()
+    if td.is_initialized():
+        td.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------ main
+def timed_steps(env, pool, steps, torch):
+    """(device ms, wall s) of `steps` back-to-back step() calls (no autoreset boundary inside)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        env.step(pool[i & 15])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1), time.perf_counter() - t0
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
         print(json.dumps(_cpu_worker(tuple(json.loads(sys.argv[2])))))
-        return
+        return 0
     args = parse()
-    import numpy as np
-    import torch
-
-    from weather2alert_amd import HeatAlertVecEnv, dist as wdist, synth, tables
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # before anything imports torch / initialises a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        print(f"bench.py: --gpus {args.gpus} needs one process per GPU (python -m torch.distributed.run --nnodes=1 "
-              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...); running on 1 GPU",
-              file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    if args.workload == "launcher_stub":
+        return run_stub(args, rank, world)
+
+    import numpy as np
+    import torch
+
+    from weather2alert_amd import HeatAlertVecEnv, build as wbuild, dist as wdist, synth, tables
+
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (use --workload launcher_stub --backend gloo to " \
+                                      "rehearse the launcher without one)"
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if args.backend == 'gloo' else local}")
     torch.cuda.set_device(device)
     wdist.init_from_env(args.backend, device)
 
-    wname, n_default, augment, rpath, desc = WORKLOADS[args.workload]
+    wname, n_default, augment, desc = WORKLOADS[args.workload]
     n = args.num_envs or n_default
     if args.scaling == "strong":
         start, stop = wdist.shard_range(n, rank, world)
@@ -197,12 +323,9 @@ def main():
                           extra_confounder_fips=60)
     ct = tables.compile_from_synth(sd)
     dt = tables.DeviceTables(ct, device)
-    if rpath == "table":
-        dt.build_logit_table(timed=True)
     env = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, env_gid0=rank * n,
-                          write_obs=not args.no_obs, reward_path=rpath, episode_order=args.episode_order,
-                          lockstep=False if args.graph else None,
-                          obs_dtype=torch.float16 if args.obs_f16 else torch.float32)
+                          write_obs=not args.no_obs, episode_order=args.episode_order,
+                          lockstep=False if args.graph else None, step_kernel=args.step_kernel)
     gather = wdist.ReturnGatherer(n, device)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
@@ -211,17 +334,29 @@ def main():
     t_setup = time.perf_counter() - t_setup
     T = ct.T
     stepno = 0
+    coll_ev = []
+
+    def gather_returns():
+        if world > 1:  # device time of the collective, on the launch stream
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            gather.gather(env._final_return)
+            c1.record()
+            coll_ev.append((c0, c1))
+        else:
+            gather.gather(env._final_return)
 
     def one_step():
         nonlocal stepno
         env.step(pool[stepno & 15])
         stepno += 1
         if stepno % T == 0:  # lock step: every env just finished an episode
-            gather.gather(env._final_return)
+            gather_returns()
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
+    coll_ev.clear()
     graph = None
     if args.graph:
         # hipGraph of G consecutive steps (fixed action buffers); autoreset runs inside the kernel so that
@@ -238,6 +373,7 @@ def main():
                 env.step(pool[i & 15])
         torch.cuda.synchronize()
     wdist.barrier()
+    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -250,7 +386,7 @@ def main():
             before = stepno
             stepno += args.graph
             if stepno // T != before // T:
-                gather.gather(env._final_return)
+                gather_returns()
     ev1.record()
     torch.cuda.synchronize()
     wdist.barrier()
@@ -259,71 +395,108 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     status = env.check_status()
     mean_ret = float(gather.mean(env._final_return).item())
+    collective_ms = (sum(a.elapsed_time(b) for a, b in coll_ev) / len(coll_ev)) if coll_ev else None
+
+    # step-kernel launch time, live: HIP events on the launch stream around back-to-back launches inside one
+    # episode (no reset kernel, no collective in between); rocprofv3 --kernel-trace of this command must agree
+    kernel_us = None
+    if graph is None:
+        k_steps = min(T - 2, 140)
+        if env._host_auto and T - env._steps_in_episode <= k_steps:
+            for _ in range(T - env._steps_in_episode):
+                env.step(pool[0])  # finish this episode: the measurement must not contain a reset kernel
+        kms, _ = timed_steps(env, pool, k_steps, torch)
+        kernel_us = kms * 1e3 / k_steps
 
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
-        per_launch_s = dev_ms * 1e-3 / args.steps
-        bytes_per = ALGO_BYTES_NO_OBS if args.no_obs else ALGO_BYTES_PER_ENV_STEP
-        if rpath == "table":
-            bytes_per = ALGO_BYTES_TABLE - (116 if args.no_obs else 0)
-        achieved = bytes_per * n / per_launch_s / 1e9
-        traffic = None
+        per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
+        cb = compulsory_bytes(ct.n_obs, not args.no_obs)
+        achieved = cb["total"] * n / per_launch_s / 1e9
+        variant = "k_step64" if (env.step_kernel == "auto" and not env._dev_auto and not env.fixes) else "k_step"
+        kname = f"{variant}<obs={not args.no_obs}>" + (" (in-kernel autoreset)" if env._dev_auto else
+                                                         " + k_reset once per episode")
+        # fabric traffic from the PMC passes, only if collected on these very kernel sources
+        src_sha = wbuild.source_sha()
+        traffic = traffic_note = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(args.workload)
+                ent = json.load(open(tp)).get(args.workload + ("_noobs" if args.no_obs else ""))
             except Exception:  # noqa: BLE001
-                traffic = None
+                ent = None
+            if isinstance(ent, dict) and ent.get("src_sha") == src_sha and ent.get("step_kernel") == variant:
+                traffic = ent
+            elif ent is not None:
+                traffic_note = "profiles/traffic_latest.json was collected on other kernel sources: not reported"
         out = {
             "metric": "env_steps_per_sec", "value": total_env_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64" , "data": "synthetic",
+            "dtype": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward", "data": "synthetic",
             "config": {"workload": desc, "num_envs_per_gpu": n, "num_envs_total": n * world,
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
-                       "arithmetic": "f32 tables, fp64 logit accumulation, f32 sigmoid/reward",
-                       "seed_mode": "device", "autoreset": "same_step", "reward_path": rpath, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
-                       "obs_dtype": "f16" if args.obs_f16 else "f32",
-                       "logit_table_build_ms": dt.logit_build_ms,
-                       "logit_table_gb": None if dt.L is None else dt.L.numel() * 8 / 1e9,
-                       "collective": "all_gather_into_tensor(f32[num_envs]) per episode" if world > 1 else "none"},
+                       "policy": "Bernoulli(0.1) actions from a device RNG, table budgets",
+                       "seed_mode": "device", "autoreset": "same_step", "reward_path": "gather",
+                       "step_kernel": variant, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
+                       "collective": "all_gather_into_tensor(f32[num_envs_per_gpu]) per episode" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"k_step<autoreset={env._dev_auto},obs={not args.no_obs},table={rpath == 'table'}>"
-                                   + ("" if env._dev_auto else " + k_reset once per episode"),
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "measured_traffic_gbs": None if traffic is None else traffic / per_launch_s / 1e9,
-                         "note": "achieved uses SURVEY 8d algorithmic bytes (489 B: what the reference's step reads and "
-                                 "writes). It can exceed the HBM peak because the day slice of X is served by L2 and W "
-                                 "by the Infinity Cache, and because this kernel fetches the 112-B effectiveness row "
-                                 "only on alert days (eff enters the reward through eff*actual); measured_traffic_gbs "
-                                 "is what actually crossed the fabric",
-                         "avg_launch_us": per_launch_s * 1e6,
-                         "algorithmic_bytes_per_env_step": bytes_per,
-                         "timing": "HIP events on the launch stream around the timed steps / steps"},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic["bytes_per_launch"],
+                         "kernel": kname, "avg_launch_us": per_launch_s * 1e6,
+                         "bytes_model": "compulsory", "compulsory_bytes_per_env_step": cb,
+                         "units_per_launch": n,
+                         "traffic_unit": "fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts "
+                                         "Infinity-Cache hits, so it is an upper bound on HBM bytes)",
+                         "traffic_ratio": None if traffic is None else traffic["bytes_per_launch"] / (cb["total"] * n),
+                         "traffic_source": None if traffic is None else
+                         {k: traffic.get(k) for k in ("read_bytes_per_launch", "write_bytes_per_launch",
+                                                      "kernel_avg_us", "src_sha", "commit", "profile")},
+                         "traffic_note": traffic_note, "kernel_src_sha": src_sha,
+                         "frac_of_measured_copy_bw": achieved / 6290.0,
+                         "survey_8d_model": {"bytes_per_env_step": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"],
+                                             "gbs": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"] * n
+                                             / per_launch_s / 1e9,
+                                             "note": "SURVEY 8d charges a 100-B feature row and two 112-B coefficient "
+                                                     "rows per env-step to HBM; they are cache-resident, so this "
+                                                     "figure is not an HBM rate and may exceed the peak"},
+                         "timing": "HIP events on the launch stream around back-to-back step launches inside one "
+                                   "episode / launches"},
             "kernel_env_steps_per_sec_per_gpu": n / per_launch_s,
+            "rccl_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "collective_ms": collective_ms,
             "status_bits": status, "mean_final_return": mean_ret, "setup_s": t_setup,
         }
         if world == 1 and args.episode_order == "iid" and not args.graph and not args.no_extras:
-            # reported extra (not the headline): the opt-in relabelled episode order, same workload
             env.close()
-            e2 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment, reward_path=rpath,
-                                 write_obs=not args.no_obs, episode_order="sorted")
+            # (1) policy-pessimistic case in the same run: every env alerts every day with budget 153, so both
+            # coefficient rows are fetched on every env-step (the headline policy fetches the second one on ~6 %)
+            e2 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                                 write_obs=not args.no_obs, budget=T, step_kernel=args.step_kernel)
             e2.reset(seed=args.seed)
-            for i in range(10):
-                e2.step(pool[i & 15])
-            torch.cuda.synchronize()
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record()
-            for i in range(T):
-                e2.step(pool[i & 15])
-            s1.record()
-            torch.cuda.synchronize()
-            us = s0.elapsed_time(s1) * 1e3 / T
-            out["sorted_episode_order"] = {"ms_per_step": us * 1e-3, "value": n / us * 1e6, "unit": "env-steps/s",
-                                           "note": "opt-in episode_order='sorted': same episode multiset, env indices "
-                                                   "relabelled by table row after each reset (incl. the sort)"}
+            ones = [torch.ones(n, dtype=torch.int32, device=device)] * 16
+            timed_steps(e2, ones, 10, torch)
+            kms, _ = timed_steps(e2, ones, 130, torch)
+            us = kms * 1e3 / 130
+            out["always_alert_policy"] = {
+                "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
+                "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": "budget=153 and action=1 every day: both 128-B coefficient rows are gathered on every "
+                        "env-step (worst case for the policy-dependent effectiveness-row skip)"}
             e2.close()
+            # (2) the opt-in relabelled episode order, same workload
+            e3 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                                 write_obs=not args.no_obs, episode_order="sorted", step_kernel=args.step_kernel)
+            e3.reset(seed=args.seed)
+            timed_steps(e3, pool, 10, torch)
+            kms, _ = timed_steps(e3, pool, 130, torch)
+            us = kms * 1e3 / 130
+            out["sorted_episode_order"] = {
+                "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
+                "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
+                        "row after each reset"}
+            e3.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
             procs = min(16, os.cpu_count() or 1)
@@ -336,7 +509,8 @@ def main():
     wdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

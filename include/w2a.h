@@ -54,9 +54,11 @@ enum { W2A_ACT_I32 = 0, W2A_ACT_I64 = 1, W2A_ACT_U8 = 2 };
 enum {
   W2A_STEP_AUTORESET = 1, /* same-step autoreset with the device RNG (needs w2a_set_autoreset) */
   W2A_STEP_NO_OBS = 2,    /* reward-only: skip the observation write */
-  W2A_STEP_TABLE = 4      /* logits from the precomputed table L (+ Wendo) instead of the coefficient-row gather;
+  W2A_STEP_TABLE = 4,     /* logits from the precomputed table L (+ Wendo) instead of the coefficient-row gather;
                              only for episodes whose coefficient column is the weather county's own (no
                              similar_climate_counties augmentation) */
+  W2A_STEP_CLASSIC = 8    /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
+                             results up to the order of the fp64 additions; for A/B measurements and tests) */
 };
 
 /* budget sampling of reset(sample_budget=..., sample_budget_type=...), env.py:172-177 */

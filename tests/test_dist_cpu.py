@@ -76,3 +76,43 @@ def test_single_process_gatherer_is_a_copy():
     x = torch.arange(5, dtype=torch.float32)
     assert torch.equal(g.gather(x), x)
     assert float(g.mean(x)) == 2.0
+
+
+@pytest.mark.timeout(180)
+def test_bench_launches_itself_for_several_ranks():
+    """`python bench.py --gpus 2` without a launcher starts one child per rank (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) before anything touches a GPU and forwards rank 0's JSON line; rehearsed on gloo with the stub
+    workload (no env stepping, no GPU): process group of 2, per-episode return all-gather, max-over-ranks timing."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--workload", "launcher_stub", "--steps", "306", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=170)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2 and out["gather_ok"] and out["stub"]
+    assert out["steps"] == 306 and out["collective_ms"] is not None and out["scaling"] == "weak"
+    # a mismatching launcher environment is refused, not silently benchmarked on one rank
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "launcher_stub",
+                          "--backend", "gloo"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         timeout=60)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_bench_defaults_follow_baseline_configs():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.parse([]).workload == "configs2" and b.parse(["--gpus", "8"]).workload == "configs4"
+    assert b.WORKLOADS["configs4"][:3] == ("nn_full_medicare_all", 1048576, False)
+    cb = b.compulsory_bytes(29, True)
+    assert cb["total"] == 161 and b.compulsory_bytes(29, False)["total"] == 45

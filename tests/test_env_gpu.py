@@ -159,6 +159,48 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, path):
     env.close()
 
 
+@pytest.mark.parametrize("n,write_obs", [(64, True), (1000 + 37, True), (4096 + 5, False), (33, True)])
+def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
+    """The 64-envs-per-wave kernel against the 4-lanes-per-env kernel on the same batch: integer state and
+    observations identical, rewards equal up to the order of the fp64 additions; ragged tails (n not a
+    multiple of 64 or 32), ragged episode lengths (stale terminal observations, Q6) and bad actions."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=20, years=[2006, 2007, 2008], n_samples=9, seed=41, extra_confounder_fips=3)
+    rng = np.random.default_rng(n)
+    nd = rng.integers(140, 154, size=(20, 3))
+    sd.meta["n_days_per_episode"] = nd
+    ct = tables.compile_from_synth(sd)
+    ep = _random_tuples(ct, n, rng, True)
+    kw = dict(tables=ct, device=dev, autoreset="disabled", write_obs=write_obs)
+    new, old = HeatAlertVecEnv(n, **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
+    o1, _ = new.reset(options={"episodes": ep})
+    o2, _ = old.reset(options={"episodes": ep})
+    assert torch.equal(o1, o2)
+    fin = torch.zeros(n, dtype=torch.bool, device=dev)
+    for t in range(153):
+        a = torch.as_tensor((rng.random(n) < 0.3).astype(np.int32), device=dev)
+        a[fin] = 0
+        o1, r1, d1, _, _ = new.step(a)
+        o2, r2, d2, _, _ = old.step(a)
+        live = ~fin
+        assert torch.equal(d1[live], d2[live]) and torch.equal(o1, o2)
+        assert torch.allclose(r1[live], r2[live], rtol=0, atol=1e-6)
+        fin |= d1
+    s1, s2 = new.state(), old.state()
+    for k in ("t", "used", "streak", "hist14", "last_actual", "at_budget", "finished"):
+        assert torch.equal(s1[k], s2[k]), k
+    assert torch.allclose(s1["episode_return"], s2["episode_return"], rtol=1e-5)
+    assert torch.allclose(new._final_return, old._final_return, rtol=1e-5)
+    # finished envs were stepped on (autoreset disabled): both kernels flag it, neither faults
+    assert new.check_status() == old.check_status() == 4  # W2A_ST_STEP_AFTER_DONE
+    new.step(torch.full((n,), 2, dtype=torch.int64, device=dev))  # bad action on top
+    with pytest.raises(ValueError):
+        new.check_status()
+    new.close()
+    old.close()
+
+
 def test_logit_table_matches_float64_contraction(dev):
     """The grouped fp64-MFMA precompute (k_logit_table) against a NumPy float64 einsum: every
     (day, county, year, posterior draw, head), gate folded in as -inf; and the packed run-time-slot rows."""
@@ -283,10 +325,11 @@ def test_same_step_autoreset_and_shard_invariance(dev, path, lockstep):
         outs = [p.step(a[s].to(dev)) for p, s in zip(parts, (slice(0, h), slice(h, n)))]
         assert torch.equal(o, torch.cat([x[0] for x in outs]))
         r_parts = torch.cat([x[1] for x in outs])
-        if path == "gather":
-            assert torch.equal(r, r_parts)
-        else:  # second shard runs the row-gather kernel: table vs gather agree to f32 rounding of the sigmoid input
-            assert torch.allclose(r, r_parts, rtol=0, atol=2e-6)
+        if path == "gather":  # second shard: same kernel variant as `full` -> bit-identical rewards
+            assert torch.equal(r[h:], outs[1][1])
+        # first shard: the other autoreset implementation, i.e. the other step kernel (different order of the fp64
+        # additions); table vs gather agree to f32 rounding of the sigmoid input
+        assert torch.allclose(r, r_parts, rtol=0, atol=2e-6)
         assert torch.equal(d, torch.cat([x[2] for x in outs]))
         if t < 153:
             ret += r.cpu().double()
@@ -832,7 +875,7 @@ def test_half_precision_observations_opt_in(dev):
     sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=12)
     ct = tables.compile_from_synth(sd)
     n = 1000 + 7
-    a32 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+    a32 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, step_kernel="classic")
     a16 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, obs_dtype=torch.float16)
     o32, _ = a32.reset(seed=3)
     o16, _ = a16.reset(seed=3)

@@ -22,14 +22,16 @@ p.add_argument("--workload", default="configs2")
 p.add_argument("--steps", type=int, default=24)
 p.add_argument("--num-envs", type=int, default=None)
 p.add_argument("--no-obs", action="store_true")
+p.add_argument("--step-kernel", default="auto", choices=["auto", "classic"])
+p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"])
 a = p.parse_args()
-wname, n_default, augment, rpath, desc = bench.WORKLOADS[a.workload]
+wname, n_default, augment, desc = bench.WORKLOADS[a.workload]
 n = a.num_envs or n_default
 dev = torch.device("cuda:0")
 sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
 env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs,
-                      reward_path=rpath)
+                      step_kernel=a.step_kernel, episode_order=a.episode_order)
 g = torch.Generator(device=dev).manual_seed(1234)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
 env.reset(seed=0)
@@ -44,5 +46,14 @@ torch.cuda.synchronize()
 for i in range(a.steps):
     env.step(pool[i & 7])
 torch.cuda.synchronize()
+import json  # noqa: E402
+
+from weather2alert_amd import build as wbuild  # noqa: E402
+
+os.makedirs("gpurun_out", exist_ok=True)
+tag = a.workload + ("_noobs" if a.no_obs else "") + ("_sorted" if a.episode_order == "sorted" else "")
+json.dump({"workload": tag, "src_sha": wbuild.source_sha(), "num_envs": n, "steps": a.steps,
+           "step_kernel": "k_step64" if a.step_kernel == "auto" else "k_step"},
+          open(f"gpurun_out/pmc_probe_{tag}.json", "w"))
 print("probe done", desc, "steps", a.steps)
 env.close()

@@ -11,7 +11,7 @@ ROW_FLOATS = 32
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE = 1, 2, 4
+STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE, STEP_CLASSIC = 1, 2, 4, 8
 ABI_VERSION = 4
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2

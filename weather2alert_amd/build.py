@@ -34,6 +34,21 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > m for d in deps)
 
 
+def source_sha() -> str:
+    """sha256 over the kernel sources and the ABI header (file names + contents): identifies the build that a
+    profile was collected on, independently of commits that do not touch the kernels."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.dirname(SRC)
+    for f in sorted(os.listdir(csrc)) + [os.path.join(INC, "w2a.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if path.endswith((".hip", ".hip.h", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB

@@ -35,6 +35,7 @@
 
 #include "w2a_common.hip.h"
 #include "w2a_step.hip.h"
+#include "w2a_step64.hip.h"
 #include "w2a_reset.hip.h"
 #include "w2a_logit_table.hip.h"
 #include "w2a_rollout.hip.h"
@@ -209,6 +210,17 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.obs_f16 = env->obs_f16;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
+#if !W2A_F64_SIGMOID
+  if (!autoreset && !table && !env->tb.fixes && !env->obs_f16 && !(flags & W2A_STEP_CLASSIC)) {
+    // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
+    const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
+    dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
+    if (no_obs) hipLaunchKernelGGL((k_step64<false>), grid64, block, 0, s, a);
+    else hipLaunchKernelGGL((k_step64<true>), grid64, block, 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return W2A_OK;
+  }
+#endif
 #define W2A_LAUNCH(AR, OB, TB) \
   do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, TB, true>), grid, block, 0, s, a); \
        else hipLaunchKernelGGL((k_step<AR, OB, TB, false>), grid, block, 0, s, a); } while (0)

@@ -1,0 +1,200 @@
+// w2a_step64.hip.h -- k_step64: one day for every env (env.py:238-262), the lean form of k_step for batches that
+// need neither the in-kernel autoreset, nor the corrected-semantics flags, nor the logit table.
+// Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
+#ifndef W2A_STEP64_HIP_H
+#define W2A_STEP64_HIP_H
+
+// Why a second geometry. k_step serves an env with a 4-lane group from start to end, so the per-env integer
+// work (budget gate, history, termination; env.py:242-260) is executed by four lanes each and a wave has only
+// 16 x 28 B of streamed state in flight during its first memory hop. Here a wave owns 64 consecutive envs and
+// changes its lane <-> env mapping between phases:
+//   A  lane = env          state + action loads (three fully coalesced streams: 768 + 768 + 256 B per wave),
+//                          budget gate / history / termination once per env, descriptors to LDS
+//   B  8 lanes = one row   two passes of 4 rounds; a round serves 8 envs, lane p of a group owns floats 4p..4p+3
+//                          of the env's 128-B feature row and coefficient row(s): every gather instruction covers
+//                          8 whole lines, a pass has 8..12 of them in flight per lane. fp64 FMA, DPP all-reduce
+//                          over the 8 lanes, logits to LDS; the lanes scatter their row fragment into the packed
+//                          observation tile (reference column order), flushed per pass as coalesced 16-B stores
+//   C  lane = env          sigmoid, reward, return accumulator; reward / done / state written as whole lines
+// What is computed is identical to k_step<false, WRITE_OBS, false, false> up to the order of the fp64 additions
+// (4-term chains + 8-lane tree instead of 8-term chains + 4-lane tree: ~1e-16 relative on the logits).
+#define S64_ENVS 64                 // envs per wave
+#define S64_WAVES (BLOCK / 64)
+#define S64_PASS_ENVS 32            // envs per observation flush (4 rounds of 8)
+#define S64_ROUNDS 4
+
+struct S64Wave {
+  uint2 desc[S64_ENVS];             // {float4 index of the feature row, float4 index of the coefficient rows | need_eff << 31}
+  float4 rt[S64_ENVS];              // run-time fields alert_lag1, alert_streak, remaining_budget, alert_2wks (slots 24..27)
+  float2 z[S64_ENVS];               // {(float) baseline logit, (float) effectiveness logit (-inf: gate closed)}
+  float tile[S64_PASS_ENVS * ROWF]; // packed observation rows of one pass (+ scratch words behind them)
+};
+
+#ifndef W2A_S64_MIN_WAVES
+#define W2A_S64_MIN_WAVES 4  // waves/SIMD the kernel is compiled for (<= 128 VGPRs)
+#endif
+template <bool WRITE_OBS>
+__global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
+  __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  S64Wave &sw = s_w[wave];
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
+  const int64_t wave_env0 = ((int64_t)lb * S64_WAVES + wave) * S64_ENVS;
+  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no workgroup barrier is used below
+
+  // ---------------------------------------------------------------- phase A: lane = env
+  const int64_t env = wave_env0 + lane;
+  const bool valid = env < a.n;
+  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: surplus lanes shadow the last env, never store
+  const u3 h = a.st.hot3[e];
+  const u3 c = a.st.stepc[e];
+  int32_t act = load_action(a, e);
+  uint32_t st_bits = 0;
+  if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
+  const uint32_t t = D0_T(h.a), used = D0_USED(h.a), streak = D0_STREAK(h.a);
+  const uint32_t hist = D1_HIST(h.b), ndays = D1_NDAYS(h.b);
+  const int32_t budget = (int32_t)c.a;
+  if (D1_FIN(h.b)) st_bits |= W2A_ST_STEP_AFTER_DONE;
+  // env.py:242-250  budget gate, history
+  const uint32_t atb = ((int32_t)used == budget) ? 1u : 0u;
+  const uint32_t actual = (act == 1 && atb) ? 0u : (uint32_t)act;
+  const uint32_t used2 = used + actual;
+  const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+  const bool done = (t + 1 >= ndays);  // env.py:256
+  {
+    // feature row of day t (pre-increment, Q6) and the env's coefficient rows, as float4 indices (32-bit: table
+    // sizes are validated in w2a_create). The effectiveness row is fetched only on alert days (k_step).
+    const uint32_t day_row = t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b;
+    const uint32_t wrow = W_COL(c.c) * (uint32_t)a.tb.n_samples + W_SAMPLE(c.c);
+    sw.desc[lane] = make_uint2(day_row * (ROWF / 4), (wrow * (2 * ROWF / 4)) | (actual << 31));
+    // env.py:190-193: alert_lag1 = today's action for t > 0 (Q3), streak before today's action (Q4),
+    // remaining budget after it, the agent's 14-day count (Q1)
+    sw.rt[lane] = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak, (float)(budget - (int32_t)used2),
+                              (float)__popc(hist2));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---------------------------------------------------------------- phase B: 8 lanes = one 128-B row
+  const int p = lane & 7;   // float4 of the row owned by this lane
+  const int g = lane >> 3;  // row group: env j = pass * 32 + round * 8 + g of the wave
+  int4 so = make_int4(-1, -1, -1, -1);
+  if (WRITE_OBS) so = reinterpret_cast<const int4 *>(a.slot_obs)[p];
+  const int n_obs = a.tb.n_obs;
+  const bool write_me = valid && !done;  // a finished env keeps its stale observation (env.py:257-262, Q6)
+#pragma unroll 1
+  for (int pass = 0; pass < S64_ENVS / S64_PASS_ENVS; ++pass) {
+    if (wave_env0 + pass * S64_PASS_ENVS >= a.n) break;  // wave-uniform
+    float4 x[S64_ROUNDS], wb[S64_ROUNDS], we[S64_ROUNDS];
+    bool need[S64_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < S64_ROUNDS; ++r) {
+      const uint2 d = sw.desc[pass * S64_PASS_ENVS + r * 8 + g];
+      need[r] = (d.y >> 31) != 0u;
+      const uint32_t wq = d.y & 0x7FFFFFFFu;
+      x[r] = a.tb.X[d.x + p];
+      wb[r] = a.tb.W[wq + p];
+      we[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (need[r]) we[r] = a.tb.W[wq + ROWF / 4 + p];
+    }
+#pragma unroll
+    for (int r = 0; r < S64_ROUNDS; ++r) {
+      const int j = pass * S64_PASS_ENVS + r * 8 + g;
+      if (p == RT_QUAD) x[r] = sw.rt[j];
+      // env.py:207-217: two 28-term dot products, fp64 accumulation (products of f32 values are exact in fp64)
+      const double x0 = (double)x[r].x, x1 = (double)x[r].y, x2 = (double)x[r].z, x3 = (double)x[r].w;
+      double zb = x0 * (double)wb[r].x;
+      zb = fma(x1, (double)wb[r].y, zb);
+      zb = fma(x2, (double)wb[r].z, zb);
+      zb = fma(x3, (double)wb[r].w, zb);
+      double ze = x0 * (double)we[r].x;
+      ze = fma(x1, (double)we[r].y, ze);
+      ze = fma(x2, (double)we[r].z, ze);
+      ze = fma(x3, (double)we[r].w, ze);
+      // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds the 0/1 flag with a zero coefficient; a
+      // closed gate drives the logit to -inf so that the sigmoid is exactly 0
+      if (p == GATE_QUAD && !(x[r].z > 0.5f)) ze = -__builtin_inf();
+      zb += dpp_f64<0xB1>(zb);   // lane ^ 1
+      ze += dpp_f64<0xB1>(ze);
+      zb += dpp_f64<0x4E>(zb);   // lane ^ 2
+      ze += dpp_f64<0x4E>(ze);
+      zb += dpp_f64<0x141>(zb);  // row_half_mirror: the other quad of the 8-lane group
+      ze += dpp_f64<0x141>(ze);
+      if (p == 0) sw.z[j] = make_float2((float)zb, (float)ze);
+      if (WRITE_OBS) {
+        // branch-free scatter into the packed tile; slots that are not observation columns go to scratch words
+        const int base = (r * 8 + g) * n_obs;
+        const int trash = S64_PASS_ENVS * n_obs + (lane & 31);
+        sw.tile[so.x >= 0 ? base + so.x : trash] = x[r].x;
+        sw.tile[so.y >= 0 ? base + so.y : trash] = x[r].y;
+        sw.tile[so.z >= 0 ? base + so.z : trash] = x[r].z;
+        sw.tile[so.w >= 0 ? base + so.w : trash] = x[r].w;
+      }
+    }
+    if (WRITE_OBS) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t env0 = wave_env0 + pass * S64_PASS_ENVS;
+      float *dst = reinterpret_cast<float *>(a.obs) + env0 * n_obs;
+      // which envs of this pass write: their phase-A lanes are pass*32 .. pass*32+31
+      const unsigned long long wm_all = __ballot(write_me);
+      const uint32_t wm = (uint32_t)(wm_all >> (pass * S64_PASS_ENVS));
+      const bool full = env0 + S64_PASS_ENVS <= a.n;
+      if (full && wm == 0xFFFFFFFFu) {
+        const int chunks = (S64_PASS_ENVS * n_obs) >> 2;  // 32 * n_obs floats: a multiple of 4
+#pragma unroll
+        for (int c0 = 0; c0 < (S64_PASS_ENVS * ROWF) / 4; c0 += 64) {
+          const int ch = c0 + lane;
+          if (ch < chunks) {
+            const v4f v = reinterpret_cast<const v4f *>(sw.tile)[ch];
+#if W2A_NT_OBS
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(dst) + ch);
+#else
+            reinterpret_cast<v4f *>(dst)[ch] = v;
+#endif
+          }
+        }
+      } else if (wm != 0u) {
+        // ragged tail, or some env of the pass keeps its stale row: element-wise, masked
+        const int total = S64_PASS_ENVS * n_obs;
+        for (int i = lane; i < total; i += 64) {
+          const int jj = i / n_obs;
+          if ((wm >> jj) & 1u) dst[i] = sw.tile[i];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (!WRITE_OBS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // ---------------------------------------------------------------- phase C: lane = env
+  if (!valid) return;
+  const float2 z = sw.z[lane];
+  const float base = sigmoid_f32(z.x);  // env.py:211-221
+  const float eff = sigmoid_f32(z.y);
+  const float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  const uint32_t t2 = done ? t : t + 1;
+  const uint32_t streak2 = done ? streak : (actual ? streak + 1 : 0);  // env.py:260
+  const float ret = __uint_as_float(h.c) + r;
+  u3 h2;
+  h2.a = pack_d0(t2, used2, streak2, actual, atb);
+  h2.b = pack_d1(hist2, ndays, done ? 1u : 0u);
+  h2.c = __float_as_uint(ret);
+  a.st.hot3[e] = h2;
+  a.reward[e] = r;
+  a.done[e] = done ? 1 : 0;
+  if (done && a.last_return) a.last_return[e] = ret;
+  if (st_bits) atomicOr(a.status, (int)st_bits);
+}
+
+#endif  // W2A_STEP64_HIP_H

@@ -74,6 +74,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
     obs_dtype            torch.float32 (default, bit-exact table values) or torch.float16 (opt-in: observations are
                          rounded to half on the way out -- half the bytes of the largest stream of a step).
+    step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches on the row-gather path run
+                         the 64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env
+                         kernel; "classic" forces the latter (same results up to the order of the fp64 additions;
+                         for A/B measurements).
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -105,6 +109,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         faithful: bool = True,
         fixes: set | list | None = None,
         obs_dtype: torch.dtype = torch.float32,
+        step_kernel: Literal["auto", "classic"] = "auto",
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -148,6 +153,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if "alert_2wks" in self.fixes and reward_path == "table":
             raise ValueError("fixes={'alert_2wks'} moves a coefficient out of the logit table; use reward_path='gather'")
         self.reward_path = reward_path
+        if step_kernel not in ("auto", "classic"):
+            raise ValueError(f"step_kernel {step_kernel!r}")
+        self.step_kernel = step_kernel
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
         if episode_order == "sorted" and seed_mode != "device":
@@ -250,6 +258,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._host_auto = self.autoreset == "same_step" and self.seed_mode == "device" and self._lockstep
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
                             (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
+                            (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
 
     def _stream(self):
