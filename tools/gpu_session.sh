@@ -20,7 +20,39 @@ for step in "$@"; do
         timeout -k 10 300 python tools/exp_step_kernels.py --quick --kernels auto 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/ab_step64.log
       done
       python -c "from weather2alert_amd import build; build.build_lib(force=True)" ;;
+    ab2)
+      # AB_FLAGS="flagsA;flagsB;..."  -> bench.py kernel times (iid / always-alert / sorted) per build
+      IFS=';' read -ra FL <<< "$AB_FLAGS"
+      for flags in "${FL[@]}"; do
+        echo "=== W2A_CXXFLAGS=$flags" | tee -a gpurun_out/ab2.log
+        W2A_CXXFLAGS="$flags" python -c "from weather2alert_amd import build; build.build_lib(force=True)" || exit 1
+        timeout -k 10 300 python bench.py --no-cpu-baseline --steps 612 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iid %.2f us  always-alert %.2f us  sorted %.2f us  e2e %.2f G/s' % (d['roofline']['avg_launch_us'], d['always_alert_policy']['kernel_us'], d['sorted_episode_order']['kernel_us'], d['value']/1e9))" | tee -a gpurun_out/ab2.log
+      done
+      python -c "from weather2alert_amd import build; build.build_lib(force=True)" ;;
     bench)
-      timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-1500 ;;
+      timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-3000 ;;
+    benchab)
+      for k in auto classic; do
+        timeout -k 10 300 python bench.py --step-kernel $k --no-extras --no-cpu-baseline > gpurun_out/bench_$k.log 2>&1
+        echo "bench $k exit $?"; tail -1 gpurun_out/bench_$k.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'])"
+      done ;;
+    prof:*)
+      # prof:<workload>[:sorted]  -- kernel trace of bench.py + PMC passes of tools/pmc_probe.py (one pass per counter
+      # group, never combined with trace domains other than --kernel-trace)
+      IFS=: read -r _ w order <<< "$step"
+      tag=$w; extra=""; bextra=""
+      if [ "$order" == "sorted" ]; then tag=${w}_sorted; extra="--episode-order sorted"; bextra="--episode-order sorted"; fi
+      R=$PWD
+      rm -rf gpurun_out/prof_*_$tag
+      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt_$tag -- python3 bench.py --workload $w $bextra --no-cpu-baseline > gpurun_out/prof_kt_$tag.log 2>&1; echo "prof_kt $tag exit $?"
+      for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "sq2:SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+        name=${grp%%:*}; ctrs=${grp#*:}
+        timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w $extra > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
+      done
+      for d in prof_kt prof_fetch prof_write prof_tcc prof_sq prof_sq2; do
+        python tools/rocprof_summary.py gpurun_out/${d}_$tag --json gpurun_out/${d}_$tag.summary.json > gpurun_out/${d}_$tag.summary.txt 2>&1
+        find gpurun_out/${d}_$tag -name "*.csv" -size +2M -delete
+      done
+      head -3 gpurun_out/prof_kt_$tag.summary.txt | cut -c1-300 ;;
   esac
 done

@@ -30,6 +30,29 @@ struct S64Wave {
   float tile[S64_PASS_ENVS * ROWF]; // packed observation rows of one pass (+ scratch words behind them)
 };
 
+// Store cache policy (A/B): bit 0 = observation rows, bit 1 = reward / done / state leave with `sc1`
+// (write-through: the line is not kept in the XCD's L2, MI355X_MICROARCH.md "stores of each flavour"), so the
+// streamed outputs do not evict the coefficient rows the gathers want to find there. 0 = nt observation stores.
+#ifndef W2A_S64_SC1
+#define W2A_S64_SC1 0
+#endif
+#ifndef W2A_S64_NT_STATE
+#define W2A_S64_NT_STATE 0  // A/B: bit 0 = hot3, bit 1 = stepc loaded non-temporally
+#endif
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void st16_sc1(void *p, v4f v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st12_sc1(void *p, v3u v) {
+  asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st4_sc1(void *p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
+  asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 #ifndef W2A_S64_MIN_WAVES
 #define W2A_S64_MIN_WAVES 4  // waves/SIMD the kernel is compiled for (<= 128 VGPRs)
 #endif
@@ -48,8 +71,18 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   const int64_t env = wave_env0 + lane;
   const bool valid = env < a.n;
   const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: surplus lanes shadow the last env, never store
+#if W2A_S64_NT_STATE & 1
+  const v3u hv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.hot3[e]));
+  u3 h; h.a = hv.x; h.b = hv.y; h.c = hv.z;
+#else
   const u3 h = a.st.hot3[e];
+#endif
+#if W2A_S64_NT_STATE & 2
+  const v3u cv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.stepc[e]));
+  u3 c; c.a = cv.x; c.b = cv.y; c.c = cv.z;
+#else
   const u3 c = a.st.stepc[e];
+#endif
   int32_t act = load_action(a, e);
   uint32_t st_bits = 0;
   if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
@@ -151,7 +184,9 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
           const int ch = c0 + lane;
           if (ch < chunks) {
             const v4f v = reinterpret_cast<const v4f *>(sw.tile)[ch];
-#if W2A_NT_OBS
+#if W2A_S64_SC1 & 1
+            st16_sc1(reinterpret_cast<v4f *>(dst) + ch, v);
+#elif W2A_NT_OBS
             __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(dst) + ch);
 #else
             reinterpret_cast<v4f *>(dst)[ch] = v;
@@ -190,9 +225,15 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   h2.a = pack_d0(t2, used2, streak2, actual, atb);
   h2.b = pack_d1(hist2, ndays, done ? 1u : 0u);
   h2.c = __float_as_uint(ret);
+#if W2A_S64_SC1 & 2
+  st12_sc1(&a.st.hot3[e], v3u{h2.a, h2.b, h2.c});
+  st4_sc1(&a.reward[e], __float_as_uint(r));
+  st1_sc1(&a.done[e], done ? 1u : 0u);
+#else
   a.st.hot3[e] = h2;
   a.reward[e] = r;
   a.done[e] = done ? 1 : 0;
+#endif
   if (done && a.last_return) a.last_return[e] = ret;
   if (st_bits) atomicOr(a.status, (int)st_bits);
 }
