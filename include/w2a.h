@@ -57,8 +57,11 @@ enum {
   W2A_STEP_TABLE = 4,     /* logits from the precomputed table L (+ Wendo) instead of the coefficient-row gather;
                              only for episodes whose coefficient column is the weather county's own (no
                              similar_climate_counties augmentation) */
-  W2A_STEP_CLASSIC = 8    /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
+  W2A_STEP_CLASSIC = 8,   /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
+  W2A_STEP_REWARD_GIVEN = 16 /* `reward` is an INPUT: it already holds today's reward of every env
+                             (w2a_posterior_mean_reward on the same state and actions); the step does everything
+                             else of env.py:238-262 and accumulates that reward into the episode return */
 };
 
 /* budget sampling of reset(sample_budget=..., sample_budget_type=...), env.py:172-177 */
@@ -178,6 +181,21 @@ int w2a_build_logit_table(const w2a_tables *tables, void *L, size_t L_bytes, voi
  * workspace: caller-owned, w2a_sort_workspace_bytes(num_envs) bytes, 256-B aligned. */
 size_t w2a_sort_workspace_bytes(int64_t num_envs);
 int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream);
+
+/* reward_mode = "posterior_mean" (the legacy env's eval mode, _deprecated/env.py:332-342: `posterior_indices =
+ * np.arange(n_posterior_samples) if eval_mode`, `np.mean([_get_reward(i, ...)])`, on today's reward form
+ * env.py:197-226): the reward of every env is the mean over ALL posterior draws of its coefficient column
+ * instead of the one draw of the episode. One grouped fp64-MFMA GEMM per step: per column
+ * [envs x 32 slots] * [32 slots x 2 heads x n_samples draws], sigmoid / gate / mean epilogue.
+ *   w2a_group_by_column        after EVERY reset: sorts the env ids by coefficient column into `workspace`
+ *                              (caller-owned, w2a_group_workspace_bytes(num_envs), 256-B aligned, must stay alive
+ *                              while w2a_posterior_mean_reward is used);
+ *   w2a_posterior_mean_reward  before w2a_step(..., W2A_STEP_REWARD_GIVEN) with the SAME actions: writes
+ *                              reward [num_envs] f32 from the pre-step state. Same budget gate as the step
+ *                              (env.py:242-246): an alert attempted at budget counts as no alert. */
+size_t w2a_group_workspace_bytes(int64_t num_envs);
+int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
+int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream);
 
 /* Opt-in observation format (no reference counterpart). W2A_OBS_F32 (default): obs buffers are float32
  * [num_envs][n_obs], bit-exact copies of the table values. W2A_OBS_F16: the `obs` pointers of w2a_reset*,

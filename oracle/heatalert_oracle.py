@@ -164,7 +164,13 @@ class RefData:
 class OracleEnv:
     """Scalar restatement of HeatAlertEnv; attribute names follow the reference."""
 
-    def __init__(self, data: RefData, similar_climate_counties: bool = False, budget: int | None = None):
+    def __init__(self, data: RefData, similar_climate_counties: bool = False, budget: int | None = None,
+                 eval_mode: bool = False):
+        # eval_mode: the LEGACY env's evaluation switch (_deprecated/env.py:64,332-342): the step reward is the mean
+        # over ALL posterior draws instead of the episode's one draw. The current env.py has no such switch; the
+        # restatement applies the legacy averaging to today's reward form (env.py:197-226). Not pinned by goldens
+        # (the legacy env computes a different functional form), only by agreement of the two restatements below.
+        self.eval_mode = eval_mode
         self.d = data
         self.similar_climate_counties = similar_climate_counties
         self.budget = budget  # env.py:34 (sticky once set, :167-170)
@@ -235,18 +241,19 @@ class OracleEnv:
         return row
 
     # env.py:197-226
-    def _get_reward(self, action):
+    def _get_reward(self, action, coef_index=None):
         li = self.location_index
+        ci = self.coef_index if coef_index is None else coef_index
         row = self._get_obs()
         s = 0  # Python sum() starts from int 0 and adds left to right in key order
         for j, c in enumerate(self._bcols):
             x = 1.0 if c < 0 else row[c]
-            s = s + x * float(self.d.wb[j, self.coef_index, li])
+            s = s + x * float(self.d.wb[j, ci, li])
         baseline = _expit(s)
         s = 0
         for j, c in enumerate(self._ecols):
             x = 1.0 if c < 0 else row[c]
-            s = s + x * float(self.d.we[j, self.coef_index, li])
+            s = s + x * float(self.d.we[j, ci, li])
         effectiveness = _expit(s) * (row[self._i_hq] > 0.5)
         reward = float(-1000 / 152 * baseline * (1 - effectiveness * action))
         if action == 1 and self.at_budget:  # dead branch: action is the *actual* action (Q5)
@@ -271,7 +278,11 @@ class OracleEnv:
         self.actual_alert_buffer.append(actual_action)
         if actual_action == 1:
             self.remaining_budget -= 1
-        reward = self._get_reward(actual_action)
+        if self.eval_mode:  # _deprecated/env.py:332-342
+            posterior_indices = np.arange(self.n_samples)
+            reward = float(np.mean([self._get_reward(actual_action, int(i)) for i in posterior_indices]))
+        else:
+            reward = self._get_reward(actual_action)
         done = self.t >= self.n_days - 1
         if not done:
             self.observation = self._get_obs()
@@ -320,7 +331,10 @@ class VectorOracle:
     Episode tuple per env: county_w (row of X), year_i, coef_col, sample, budget, n_days.
     """
 
-    def __init__(self, d: RefData, fips_weather: list[str], years: list[int], fixes=()):
+    def __init__(self, d: RefData, fips_weather: list[str], years: list[int], fixes=(), reward_mode="sampled"):
+        # reward_mode="posterior_mean": the legacy eval mode (see OracleEnv.__init__), mean over all posterior draws
+        assert reward_mode in ("sampled", "posterior_mean")
+        self.reward_mode = reward_mode
         # `fixes`: the build's opt-in corrections of reference quirks (include/w2a.h W2A_FIX_*: "alert_2wks",
         # "lag", "penalty", "obs"); they have no reference counterpart -- the empty default is the pinned,
         # reference-faithful behaviour
@@ -387,17 +401,23 @@ class VectorOracle:
         self.last_actual = actual
         self.used = self.used + actual
         row = self._get_obs(yesterday if "lag" in self.fixes else None)
-        zb = np.zeros(len(action), np.float64)
-        for j, c in enumerate(self.bcols):
-            x = 1.0 if c < 0 else row[:, c]
-            zb = zb + x * self.d.wb[j, self.sample, self.coef_col].astype(np.float64)
-        ze = np.zeros(len(action), np.float64)
-        for j, c in enumerate(self.ecols):
-            x = 1.0 if c < 0 else row[:, c]
-            ze = ze + x * self.d.we[j, self.sample, self.coef_col].astype(np.float64)
-        baseline = _expit(zb)
-        eff = _expit(ze) * (row[:, self.i_hq] > 0.5)
-        reward = -1000 / 152 * baseline * (1 - eff * actual)
+        def reward_for(sample):
+            zb = np.zeros(len(action), np.float64)
+            for j, c in enumerate(self.bcols):
+                x = 1.0 if c < 0 else row[:, c]
+                zb = zb + x * self.d.wb[j, sample, self.coef_col].astype(np.float64)
+            ze = np.zeros(len(action), np.float64)
+            for j, c in enumerate(self.ecols):
+                x = 1.0 if c < 0 else row[:, c]
+                ze = ze + x * self.d.we[j, sample, self.coef_col].astype(np.float64)
+            baseline = _expit(zb)
+            eff = _expit(ze) * (row[:, self.i_hq] > 0.5)
+            return -1000 / 152 * baseline * (1 - eff * actual)
+
+        if self.reward_mode == "posterior_mean":  # _deprecated/env.py:332-342: np.mean over every posterior index
+            reward = np.mean([reward_for(np.full(len(action), i)) for i in range(self.d.n_samples)], axis=0)
+        else:
+            reward = reward_for(self.sample)
         if "penalty" in self.fixes:
             reward = np.where((action == 1) & self.at_budget, -1.0, reward)
         done = self.t >= self.n_days - 1

@@ -921,3 +921,100 @@ def test_other_schema_parity(dev):
             assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
             np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
         env.close()
+
+
+@pytest.mark.parametrize("n,n_fips,n_samples,augment", [(3000 + 5, 48, 12, True), (37, 30, 100, False),
+                                                        (4096, 746, 100, True)])
+def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment):
+    """reward_mode='posterior_mean' (legacy eval mode, _deprecated/env.py:332-342, on today's reward form): the
+    grouped fp64-MFMA GEMM + sigmoid/mean epilogue against the oracle's mean over every posterior draw; everything
+    but the reward (observations, integer state, termination) equals the sampled-reward env. Ragged draw counts
+    (12: a partial 16-column MFMA tile), tiles that span many coefficient columns (n = 37), the full 746-column
+    table, and augmentation (Q8: the coefficient column differs from the weather county)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=n_fips, years=[2006, 2007, 2008], n_samples=n_samples, seed=19,
+                          extra_confounder_fips=5)
+    ct = tables.compile_from_synth(sd)
+    rd = O.RefData.from_synth(sd)
+    V = O.VectorOracle(rd, sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    rng = np.random.default_rng(n)
+    ep = _random_tuples(ct, n, rng, augment)
+    pm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean")
+    sm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    obs, _ = pm.reset(options={"episodes": ep})
+    sm.reset(options={"episodes": ep})
+    obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
+    np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+    worst, ret = 0.0, np.zeros(n)
+    steps = 153 if n <= 4096 and n_samples <= 12 or n < 100 else 40  # the NumPy oracle loops over all draws
+    for t in range(steps):
+        a = (rng.random(n) < 0.3).astype(np.int32)
+        at = torch.as_tensor(a, device=dev)
+        obs, r, done, _, _ = pm.step(at)
+        obs_s, r_s, done_s, _, _ = sm.step(at)
+        obs_o, r_o, done_o, _ = V.step(a)
+        err = np.abs(r.cpu().numpy().astype(np.float64) - r_o).max()
+        worst = max(worst, err)
+        assert err <= REWARD_TOL, (t, err)
+        assert torch.equal(obs, obs_s) and torch.equal(done, done_s)
+        np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
+        ret += r_o
+    assert not torch.equal(r, r_s)  # a different reward than the one-draw env
+    s1, s2 = pm.state(), sm.state()
+    for k in ("t", "used", "streak", "hist14", "last_actual", "at_budget", "finished"):
+        assert torch.equal(s1[k], s2[k]), k
+    np.testing.assert_allclose(s1["episode_return"].cpu().numpy(), ret, rtol=2e-5, atol=1e-4)
+    assert pm.check_status() == 0
+    with pytest.raises(ValueError):
+        pm.rollout(dict(kind="never"))
+    print(f"posterior mean n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
+    pm.close()
+    sm.close()
+
+
+def test_posterior_mean_lockstep_autoreset_and_guards(dev):
+    """The column grouping is rebuilt after every reset, including the host-driven lock-step autoreset; a stale
+    grouping is refused at the C ABI; configurations the GEMM path cannot serve are rejected up front."""
+    import ctypes as C
+
+    from weather2alert_amd import HeatAlertVecEnv, _ffi
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=20, seed=29, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    n = 700
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, reward_mode="posterior_mean")
+    assert env._lockstep
+    env.reset(seed=6)
+    rng = np.random.default_rng(2)
+    for episode in range(2):
+        st = {k: v.cpu().numpy() for k, v in env.state().items()}
+        assert (st["episode_no"] == episode).all() and (st["t"] == 0).all()
+        V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+        ret = np.zeros(n)
+        for t in range(153):
+            a = (rng.random(n) < 0.25).astype(np.int32)
+            _, r, done, _, info = env.step(torch.as_tensor(a, device=dev))
+            _, r_o, done_o, _ = V.step(a)
+            assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+            ret += r_o
+        assert done.all()
+        np.testing.assert_allclose(info["final_return"].cpu().numpy(), ret, rtol=2e-5)
+    # stale grouping: a reset through the ABI without regrouping must be refused, not silently mis-grouped
+    lib = env._lib
+    with torch.cuda.device(dev):
+        _ffi.check(lib.w2a_reset_device_rng(env._h, 1, -1, 1, -1, 0, 1, 1, None, None, env._stream()), "reset")
+        a = torch.zeros(n, dtype=torch.int32, device=dev)
+        rc = lib.w2a_posterior_mean_reward(env._h, a.data_ptr(), _ffi.ACT_I32, env._reward.data_ptr(), env._stream())
+    assert rc == -4 and b"w2a_group_by_column" in lib.w2a_last_error()
+    env.close()
+    with pytest.raises(ValueError):
+        HeatAlertVecEnv(8, tables=ct, device=dev, reward_mode="posterior_mean", fixes={"lag"})
+    with pytest.raises(ValueError):
+        HeatAlertVecEnv(8, tables=ct, device=dev, reward_mode="posterior_mean", lockstep=False)
+    e2 = HeatAlertVecEnv(8, tables=ct, device=dev, reward_mode="posterior_mean")
+    e2.reset(seed=1)
+    with pytest.raises(ValueError):  # a masked reset would need the in-kernel autoreset
+        e2.reset(seed=1, options={"mask": np.arange(8) < 4})
+    e2.close()

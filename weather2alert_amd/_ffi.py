@@ -11,7 +11,7 @@ ROW_FLOATS = 32
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE, STEP_CLASSIC = 1, 2, 4, 8
+STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE, STEP_CLASSIC, STEP_REWARD_GIVEN = 1, 2, 4, 8, 16
 ABI_VERSION = 4
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
@@ -22,7 +22,7 @@ SYMBOLS = [
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_set_semantics",
-    "w2a_set_obs_format",
+    "w2a_set_obs_format", "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
 ]
 OBS_F32, OBS_F16 = 0, 1
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
@@ -112,6 +112,12 @@ def load(build_if_missing: bool = True):
     lib.w2a_sort_workspace_bytes.argtypes = [i64]
     lib.w2a_sort_episodes.restype = C.c_int
     lib.w2a_sort_episodes.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
+    lib.w2a_group_workspace_bytes.restype = C.c_size_t
+    lib.w2a_group_workspace_bytes.argtypes = [i64]
+    lib.w2a_group_by_column.restype = C.c_int
+    lib.w2a_group_by_column.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.w2a_posterior_mean_reward.restype = C.c_int
+    lib.w2a_posterior_mean_reward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.w2a_observe.restype = C.c_int
     lib.w2a_observe.argtypes = [vp, vp, vp]
     lib.w2a_set_obs_format.restype = C.c_int

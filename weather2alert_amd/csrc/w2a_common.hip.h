@@ -163,6 +163,8 @@ struct w2a_env {
   ResetCfg autoreset;
   int has_autoreset;
   int32_t obs_slot_host[ROWF];
+  const uint32_t *perm;  // env ids sorted by coefficient column (w2a_group_by_column), valid until the next reset
+  int perm_valid;
 };
 
 static thread_local char g_err[512] = "";

@@ -36,6 +36,7 @@
 #include "w2a_common.hip.h"
 #include "w2a_step.hip.h"
 #include "w2a_step64.hip.h"
+#include "w2a_posterior.hip.h"
 #include "w2a_reset.hip.h"
 #include "w2a_logit_table.hip.h"
 #include "w2a_rollout.hip.h"
@@ -120,6 +121,8 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->status = status;
   h->has_autoreset = 0;
   h->obs_f16 = 0;
+  h->perm = nullptr;
+  h->perm_valid = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -141,6 +144,7 @@ static unsigned grid_for(int64_t n) {
 }
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
+  if (a.from_tuples != 2) env->perm_valid = 0;  // new episode tuples: the column grouping is stale
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.obs_f16 = env->obs_f16;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
@@ -196,6 +200,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
   const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
   const bool table = (flags & W2A_STEP_TABLE) != 0;
+  const bool given = (flags & W2A_STEP_REWARD_GIVEN) != 0;
+  if (given && (autoreset || table || env->tb.fixes || env->obs_f16 || (flags & W2A_STEP_CLASSIC)))
+    return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is served by the 64-envs-per-wave kernel only (no in-kernel "
+                             "autoreset, no logit table, no corrected-semantics flags, f32 observations)");
   if (table && !env->tb.L) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_TABLE needs tables with L/Wendo (w2a_build_logit_table)");
   if (table && autoreset && env->autoreset.augment)
     return fail(W2A_ERR_ARG, "w2a_step: the logit-table path cannot serve similar_climate_counties episodes");
@@ -210,13 +218,20 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.obs_f16 = env->obs_f16;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
-#if !W2A_F64_SIGMOID
+#if W2A_F64_SIGMOID
+  if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
+#else
   if (!autoreset && !table && !env->tb.fixes && !env->obs_f16 && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
     const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
-    if (no_obs) hipLaunchKernelGGL((k_step64<false>), grid64, block, 0, s, a);
-    else hipLaunchKernelGGL((k_step64<true>), grid64, block, 0, s, a);
+    if (given) {
+      if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
+      else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
+    } else {
+      if (no_obs) hipLaunchKernelGGL((k_step64<false, false>), grid64, block, 0, s, a);
+      else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
     return W2A_OK;
   }
@@ -319,6 +334,57 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
   if (env->st.rtw) HIP_TRY(hipMemcpyAsync(env->st.rtw, rtw_t, 32 * n, hipMemcpyDeviceToDevice, s));
+  return W2A_OK;
+}
+
+static size_t cub_group_bytes(int64_t n) {
+  size_t b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+  return b;
+}
+
+size_t w2a_group_workspace_bytes(int64_t num_envs) {
+  if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
+  return align256(4 * (size_t)num_envs) * 4 + align256(cub_group_bytes(num_envs));
+}
+
+int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_group_by_column: NULL argument");
+  if (workspace_bytes < w2a_group_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace must be 256-B aligned");
+  const size_t n = (size_t)env->n;
+  char *p = (char *)workspace;
+  uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first: stays valid after the call
+  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
+  uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
+  uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
+  size_t cub_bytes = cub_group_bytes(env->n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_group_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.stepc, k_in, i_in, env->n);
+  HIP_TRY(hipGetLastError());
+  int bits = 1;
+  while ((1 << bits) < env->tb.S) ++bits;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, perm, (int)n, 0, bits, s));
+  env->perm = perm;
+  env->perm_valid = 1;
+  return W2A_OK;
+}
+
+int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream) {
+  if (!env || !actions || !reward) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: NULL argument");
+  if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: bad action_dtype");
+  if (!env->perm_valid)
+    return fail(W2A_ERR_STATE, "w2a_posterior_mean_reward: call w2a_group_by_column after every reset (the grouping of "
+                               "envs by coefficient column is stale)");
+  if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: not available with corrected-semantics flags");
+  PosteriorArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tb = env->tb; a.st = env->st; a.perm = env->perm; a.actions = actions; a.act_dtype = action_dtype;
+  a.reward = reward; a.status = env->status; a.n = env->n;
+  const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
+  hipLaunchKernelGGL(k_posterior_mean, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   return W2A_OK;
 }
 

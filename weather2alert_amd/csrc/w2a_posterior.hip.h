@@ -1,0 +1,160 @@
+// w2a_posterior.hip.h -- k_posterior_mean: today's reward averaged over ALL posterior draws of the env's
+// coefficient column (the legacy env's eval mode, _deprecated/env.py:332-342, on today's linear-logistic form
+// env.py:197-226), as a grouped fp64-MFMA GEMM per coefficient column; k_group_keys feeds the grouping sort.
+// Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
+#ifndef W2A_POSTERIOR_HIP_H
+#define W2A_POSTERIOR_HIP_H
+
+// For env e with coefficient column c:   reward_e = mean_s  -(1000/152) * sigmoid(zb_s) * (1 - sigmoid(ze_s) * gate * actual)
+//     zb_s = sum_k x_k * Wb[c][s][k],   ze_s = sum_k x_k * We[c][s][k]          (k over the 32 row slots)
+// i.e. per column c one dense contraction  D_c [N_c envs][2 * n_samples] = A_c [N_c][32] * B_c [32][2 * n_samples]
+// followed by a sigmoid / product / mean epilogue. Envs are served in the order of `perm` (env ids sorted by
+// column, built once per episode by w2a_group_by_column), so a 64-row tile spans one column, rarely two:
+//   * the workgroup stages B_c (both heads, all draws: 25.6 KB of f32) in LDS once per column segment;
+//   * each of its 4 waves owns 16 rows: A fragments = the env's feature row of the day with the run-time slots
+//     patched in (the same derive_day()/runtime_fields() as the step kernel), converted f32 -> f64 in registers;
+//   * per 16-draw tile 8 + 8 v_mfma_f64_16x16x4_f64 (K = 32 slots; products of f32 values are exact in fp64, so
+//     the logits carry ~1e-16 relative error, as in the step kernels);
+//   * epilogue in the accumulator layout (lane = draw column, 4 rows per lane): f32 sigmoids as in the step
+//     kernels, closed gate = -inf logit, per-row sums over draws in fp64, 16-lane DPP all-reduce, one f32 per env.
+// The step kernel then runs with W2A_STEP_REWARD_GIVEN and does everything else of env.py:238-262.
+#define PM_ROWS 64                 // sorted positions per workgroup (16 per wave)
+#define PM_NPAD 112                // draws per staging pass (7 MFMA column tiles)
+typedef double pm_double4 __attribute__((ext_vector_type(4)));
+
+struct PosteriorArgs {
+  DevTables tb;
+  StateArrays st;
+  const uint32_t *perm;  // [n] env ids sorted by coefficient column
+  const void *actions;
+  int32_t act_dtype;
+  float *reward;
+  int32_t *status;
+  int64_t n;
+};
+
+__global__ void k_group_keys(const u3 *stepc, uint32_t *keys, uint32_t *idx, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = W_COL(stepc[i].c);
+  idx[i] = (uint32_t)i;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double pm_add_dpp(double v) { return v + dpp_f64<CTRL>(v); }
+
+__global__ __launch_bounds__(BLOCK) void k_posterior_mean(const PosteriorArgs a) {
+  __shared__ float sB[2][ROWF][PM_NPAD];         // [head][slot][draw]
+  __shared__ uint32_t s_col[PM_ROWS];            // coefficient column per row (0xFFFFFFFF: row past the end)
+  __shared__ uint32_t s_xrow[PM_ROWS];           // float index of the row's feature row
+  __shared__ float4 s_rt[PM_ROWS];               // run-time slots 24..27
+  __shared__ float s_ga[PM_ROWS];                // gate * actual (0 or 1)
+  __shared__ uint32_t s_env[PM_ROWS];
+  __shared__ double s_sum[PM_ROWS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t pos0 = (int64_t)blockIdx.x * PM_ROWS;
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const float *Wf = reinterpret_cast<const float *>(a.tb.W);
+  // ---- per-row set-up: thread r < 64 owns sorted position pos0 + r
+  if (tid < PM_ROWS) {
+    const int64_t pos = pos0 + tid;
+    uint32_t col = 0xFFFFFFFFu, xrow = 0, e = 0;
+    float4 rt = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ga = 0.0f;
+    if (pos < a.n) {
+      e = a.perm[pos];
+      const u3 h = a.st.hot3[e];
+      const u3 c = a.st.stepc[e];
+      const Day d = derive_day(h, c, load_action_raw(a.actions, a.act_dtype, e));
+      col = W_COL(c.c);
+      xrow = (d.t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b) * ROWF;
+      rt = runtime_fields(d);
+      // effectiveness enters through eff * gate * actual (env.py:218-221): slot 30 of the row is the 0/1 gate flag
+      ga = (d.actual && Xf[xrow + 30] > 0.5f) ? 1.0f : 0.0f;
+      if (d.st_bits) atomicOr(a.status, (int)d.st_bits);
+    }
+    s_col[tid] = col; s_xrow[tid] = xrow; s_rt[tid] = rt; s_ga[tid] = ga; s_env[tid] = e; s_sum[tid] = 0.0;
+  }
+  __syncthreads();
+  // ---- A fragments of this wave's 16 rows: lane l holds x[row = l & 15][slot = 4 * ks + (l >> 4)], ks = 0..7
+  const int row = wave * 16 + (lane & 15);
+  const int q = lane >> 4;
+  double af[ROWF / 4];
+  {
+    const uint32_t xr = s_xrow[row];
+    const bool live = s_col[row] != 0xFFFFFFFFu;
+#pragma unroll
+    for (int ks = 0; ks < ROWF / 4; ++ks) af[ks] = live ? (double)Xf[xr + 4 * ks + q] : 0.0;
+    const float4 rt = s_rt[row];  // k-step 6 = slots 24..27: the run-time fields replace the table's zeros
+    af[RT_QUAD] = live ? (double)(q == 0 ? rt.x : q == 1 ? rt.y : q == 2 ? rt.z : rt.w) : 0.0;
+  }
+  const int n_samples = a.tb.n_samples;
+  // ---- column segments of the tile (rows are sorted by column: a segment is a contiguous run)
+  int seg = 0;
+  while (seg < PM_ROWS) {
+    const uint32_t col = s_col[seg];  // uniform
+    if (col == 0xFFFFFFFFu) break;
+    int seg_end = seg + 1;
+    while (seg_end < PM_ROWS && s_col[seg_end] == col) ++seg_end;
+    for (int n0 = 0; n0 < n_samples; n0 += PM_NPAD) {
+      __syncthreads();  // previous users of sB are done
+      // stage B_col: W[(col * n_samples + s)][head][slot] -> sB[head][slot][s - n0]; 16-B global loads, one (draw, head) row per 8 threads
+      for (int idx = tid; idx < PM_NPAD * 2 * (ROWF / 4); idx += BLOCK) {
+        const int s = idx / (2 * (ROWF / 4)), rem = idx - s * (2 * (ROWF / 4));
+        const int head = rem / (ROWF / 4), k4 = rem - head * (ROWF / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + s < n_samples)
+          v = reinterpret_cast<const float4 *>(Wf)[((size_t)col * n_samples + n0 + s) * (2 * ROWF / 4) + head * (ROWF / 4) + k4];
+        sB[head][4 * k4][s] = v.x; sB[head][4 * k4 + 1][s] = v.y; sB[head][4 * k4 + 2][s] = v.z; sB[head][4 * k4 + 3][s] = v.w;
+      }
+      __syncthreads();
+      // does this wave hold any row of the segment? (wave-uniform)
+      const int w_lo = wave * 16, w_hi = w_lo + 16;
+      if (seg < w_hi && seg_end > w_lo) {
+        const int tiles = (min(PM_NPAD, n_samples - n0) + 15) >> 4;
+        double rs[4] = {0.0, 0.0, 0.0, 0.0};  // per accumulator row (q + 4 j) of this wave: sum over this lane's draws
+        float ga[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] = s_ga[w_lo + q + 4 * j];
+        for (int nt = 0; nt < tiles; ++nt) {
+          pm_double4 accb = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
+          const int nn = nt * 16 + (lane & 15);
+#pragma unroll
+          for (int ks = 0; ks < ROWF / 4; ++ks) {
+            const double bb = (double)sB[0][4 * ks + q][nn];
+            const double be = (double)sB[1][4 * ks + q][nn];
+            accb = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bb, accb, 0, 0, 0);
+            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], be, acce, 0, 0, 0);
+          }
+          if (n0 + nn < n_samples) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // D[row = q + 4 j][col = lane & 15]
+              const float base = sigmoid_f32((float)accb[j]);
+              const float eff = sigmoid_f32((float)acce[j]);
+              rs[j] += (double)(base * (1.0f - eff * ga[j]));
+            }
+          }
+        }
+        // sum over the 16 lanes that share q (one DPP row): xor 1, xor 2, half mirror, mirror
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double v = rs[j];
+          v = pm_add_dpp<0xB1>(v);
+          v = pm_add_dpp<0x4E>(v);
+          v = pm_add_dpp<0x141>(v);
+          v = pm_add_dpp<0x140>(v);
+          const int r = w_lo + q + 4 * j;
+          if ((lane & 15) == 0 && r >= seg && r < seg_end) s_sum[r] += v;  // rows of other segments: A x other B, dropped
+        }
+      }
+    }
+    seg = seg_end;
+  }
+  __syncthreads();
+  if (tid < PM_ROWS && s_col[tid] != 0xFFFFFFFFu)
+    a.reward[s_env[tid]] = (float)(-(1000.0 / 152.0) * s_sum[tid] / (double)n_samples);
+}
+
+#endif  // W2A_POSTERIOR_HIP_H

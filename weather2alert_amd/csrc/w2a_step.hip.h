@@ -29,10 +29,13 @@ struct StepArgs {
 // The in-kernel autoreset variants carry the episode draw and would spill at 64 VGPRs (measured 1.4x slower),
 // so they keep the compiler's own allocation; lock-step batches use the plain variant + k_reset instead.
 // FIXES: compiled-in support for the W2A_FIX_* corrections; the faithful variants carry none of that code.
+__device__ __forceinline__ int32_t load_action_raw(const void *actions, int32_t dtype, uint32_t e) {
+  if (dtype == W2A_ACT_I32) return reinterpret_cast<const int32_t *>(actions)[e];
+  if (dtype == W2A_ACT_I64) return (int32_t) reinterpret_cast<const int64_t *>(actions)[e];
+  return reinterpret_cast<const uint8_t *>(actions)[e];
+}
 __device__ __forceinline__ int32_t load_action(const StepArgs &a, uint32_t e) {
-  if (a.act_dtype == W2A_ACT_I32) return reinterpret_cast<const int32_t *>(a.actions)[e];
-  if (a.act_dtype == W2A_ACT_I64) return (int32_t) reinterpret_cast<const int64_t *>(a.actions)[e];
-  return reinterpret_cast<const uint8_t *>(a.actions)[e];
+  return load_action_raw(a.actions, a.act_dtype, e);
 }
 
 // One tile = the 16 envs of a wave, one day: everything of env.py:238-262 after the per-env state and action

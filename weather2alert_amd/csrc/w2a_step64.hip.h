@@ -23,6 +23,35 @@
 #define S64_PASS_ENVS 32            // envs per observation flush (4 rounds of 8)
 #define S64_ROUNDS 4
 
+// env.py:242-256 for one env from its packed state and today's action: budget gate, history, termination.
+// Shared by k_step64 and k_posterior_mean (which must agree on `actual` and the run-time fields).
+struct Day {
+  uint32_t t, used, streak, hist, ndays, atb, actual, used2, hist2, st_bits;
+  int32_t budget;
+  bool done;
+};
+__device__ __forceinline__ Day derive_day(const u3 h, const u3 c, int32_t act) {
+  Day d;
+  d.st_bits = 0;
+  if (act != 0 && act != 1) { d.st_bits |= W2A_ST_BAD_ACTION; act = 1; }
+  d.t = D0_T(h.a); d.used = D0_USED(h.a); d.streak = D0_STREAK(h.a);
+  d.hist = D1_HIST(h.b); d.ndays = D1_NDAYS(h.b);
+  d.budget = (int32_t)c.a;
+  if (D1_FIN(h.b)) d.st_bits |= W2A_ST_STEP_AFTER_DONE;
+  d.atb = ((int32_t)d.used == d.budget) ? 1u : 0u;          // at_budget BEFORE today's action (env.py:242)
+  d.actual = (act == 1 && d.atb) ? 0u : (uint32_t)act;       // env.py:243-246
+  d.used2 = d.used + d.actual;
+  d.hist2 = ((d.hist << 1) | d.actual) & 0x3FFFu;
+  d.done = (d.t + 1 >= d.ndays);                             // env.py:256
+  return d;
+}
+// env.py:190-193 as the row's run-time slots 24..27: alert_lag1 = today's action for t > 0 (Q3), streak before
+// today's action (Q4), remaining budget after it, the agent's 14-day count (Q1)
+__device__ __forceinline__ float4 runtime_fields(const Day &d) {
+  return make_float4((d.t > 0) ? (float)d.actual : 0.0f, (float)d.streak, (float)(d.budget - (int32_t)d.used2),
+                     (float)__popc(d.hist2));
+}
+
 struct S64Wave {
   uint2 desc[S64_ENVS];             // {float4 index of the feature row, float4 index of the coefficient rows | need_eff << 31}
   float4 rt[S64_ENVS];              // run-time fields alert_lag1, alert_streak, remaining_budget, alert_2wks (slots 24..27)
@@ -56,7 +85,9 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 #ifndef W2A_S64_MIN_WAVES
 #define W2A_S64_MIN_WAVES 4  // waves/SIMD the kernel is compiled for (<= 128 VGPRs)
 #endif
-template <bool WRITE_OBS>
+// REWARD_GIVEN: a.reward already holds today's reward (w2a_posterior_mean_reward ran on the same state and actions):
+// no coefficient gather and no logits here, the rest of env.py:238-262 as usual.
+template <bool WRITE_OBS, bool REWARD_GIVEN>
 __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
   const int tid = threadIdx.x;
@@ -83,29 +114,18 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
 #else
   const u3 c = a.st.stepc[e];
 #endif
-  int32_t act = load_action(a, e);
-  uint32_t st_bits = 0;
-  if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
-  const uint32_t t = D0_T(h.a), used = D0_USED(h.a), streak = D0_STREAK(h.a);
-  const uint32_t hist = D1_HIST(h.b), ndays = D1_NDAYS(h.b);
-  const int32_t budget = (int32_t)c.a;
-  if (D1_FIN(h.b)) st_bits |= W2A_ST_STEP_AFTER_DONE;
-  // env.py:242-250  budget gate, history
-  const uint32_t atb = ((int32_t)used == budget) ? 1u : 0u;
-  const uint32_t actual = (act == 1 && atb) ? 0u : (uint32_t)act;
-  const uint32_t used2 = used + actual;
-  const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
-  const bool done = (t + 1 >= ndays);  // env.py:256
+  const Day d = derive_day(h, c, load_action(a, e));
+  const uint32_t t = d.t, used2 = d.used2, hist2 = d.hist2, streak = d.streak, ndays = d.ndays;
+  const uint32_t actual = d.actual, atb = d.atb, st_bits = d.st_bits;
+  const int32_t budget = d.budget;
+  const bool done = d.done;
   {
     // feature row of day t (pre-increment, Q6) and the env's coefficient rows, as float4 indices (32-bit: table
     // sizes are validated in w2a_create). The effectiveness row is fetched only on alert days (k_step).
     const uint32_t day_row = t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b;
     const uint32_t wrow = W_COL(c.c) * (uint32_t)a.tb.n_samples + W_SAMPLE(c.c);
     sw.desc[lane] = make_uint2(day_row * (ROWF / 4), (wrow * (2 * ROWF / 4)) | (actual << 31));
-    // env.py:190-193: alert_lag1 = today's action for t > 0 (Q3), streak before today's action (Q4),
-    // remaining budget after it, the agent's 14-day count (Q1)
-    sw.rt[lane] = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak, (float)(budget - (int32_t)used2),
-                              (float)__popc(hist2));
+    sw.rt[lane] = runtime_fields(d);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -120,23 +140,27 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   const bool write_me = valid && !done;  // a finished env keeps its stale observation (env.py:257-262, Q6)
 #pragma unroll 1
   for (int pass = 0; pass < S64_ENVS / S64_PASS_ENVS; ++pass) {
+    if (REWARD_GIVEN && !WRITE_OBS) break;               // nothing to gather at all
     if (wave_env0 + pass * S64_PASS_ENVS >= a.n) break;  // wave-uniform
     float4 x[S64_ROUNDS], wb[S64_ROUNDS], we[S64_ROUNDS];
     bool need[S64_ROUNDS];
 #pragma unroll
     for (int r = 0; r < S64_ROUNDS; ++r) {
-      const uint2 d = sw.desc[pass * S64_PASS_ENVS + r * 8 + g];
-      need[r] = (d.y >> 31) != 0u;
-      const uint32_t wq = d.y & 0x7FFFFFFFu;
-      x[r] = a.tb.X[d.x + p];
-      wb[r] = a.tb.W[wq + p];
-      we[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (need[r]) we[r] = a.tb.W[wq + ROWF / 4 + p];
+      const uint2 ds = sw.desc[pass * S64_PASS_ENVS + r * 8 + g];
+      need[r] = (ds.y >> 31) != 0u;
+      const uint32_t wq = ds.y & 0x7FFFFFFFu;
+      x[r] = a.tb.X[ds.x + p];
+      wb[r] = we[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!REWARD_GIVEN) {
+        wb[r] = a.tb.W[wq + p];
+        if (need[r]) we[r] = a.tb.W[wq + ROWF / 4 + p];
+      }
     }
 #pragma unroll
     for (int r = 0; r < S64_ROUNDS; ++r) {
       const int j = pass * S64_PASS_ENVS + r * 8 + g;
       if (p == RT_QUAD) x[r] = sw.rt[j];
+      if (!REWARD_GIVEN) {
       // env.py:207-217: two 28-term dot products, fp64 accumulation (products of f32 values are exact in fp64)
       const double x0 = (double)x[r].x, x1 = (double)x[r].y, x2 = (double)x[r].z, x3 = (double)x[r].w;
       double zb = x0 * (double)wb[r].x;
@@ -157,6 +181,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       zb += dpp_f64<0x141>(zb);  // row_half_mirror: the other quad of the 8-lane group
       ze += dpp_f64<0x141>(ze);
       if (p == 0) sw.z[j] = make_float2((float)zb, (float)ze);
+      }
       if (WRITE_OBS) {
         // branch-free scatter into the packed tile; slots that are not observation columns go to scratch words
         const int base = (r * 8 + g) * n_obs;
@@ -214,10 +239,15 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
 
   // ---------------------------------------------------------------- phase C: lane = env
   if (!valid) return;
-  const float2 z = sw.z[lane];
-  const float base = sigmoid_f32(z.x);  // env.py:211-221
-  const float eff = sigmoid_f32(z.y);
-  const float r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  float r;
+  if (REWARD_GIVEN) {
+    r = a.reward[e];
+  } else {
+    const float2 z = sw.z[lane];
+    const float base = sigmoid_f32(z.x);  // env.py:211-221
+    const float eff = sigmoid_f32(z.y);
+    r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+  }
   const uint32_t t2 = done ? t : t + 1;
   const uint32_t streak2 = done ? streak : (actual ? streak + 1 : 0);  // env.py:260
   const float ret = __uint_as_float(h.c) + r;
@@ -231,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   st1_sc1(&a.done[e], done ? 1u : 0u);
 #else
   a.st.hot3[e] = h2;
-  a.reward[e] = r;
+  if (!REWARD_GIVEN) a.reward[e] = r;
   a.done[e] = done ? 1 : 0;
 #endif
   if (done && a.last_return) a.last_return[e] = ret;

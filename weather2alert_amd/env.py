@@ -74,6 +74,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
     obs_dtype            torch.float32 (default, bit-exact table values) or torch.float16 (opt-in: observations are
                          rounded to half on the way out -- half the bytes of the largest stream of a step).
+    reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
+                         "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
+                         coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
+                         reward form -- computed by a grouped fp64-MFMA GEMM per step (csrc/w2a_posterior.hip.h).
+                         Needs lock-step / disabled autoreset, faithful semantics, float32 observations.
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches on the row-gather path run
                          the 64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env
                          kernel; "classic" forces the latter (same results up to the order of the fp64 additions;
@@ -110,6 +115,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         fixes: set | list | None = None,
         obs_dtype: torch.dtype = torch.float32,
         step_kernel: Literal["auto", "classic"] = "auto",
+        reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -156,6 +162,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if step_kernel not in ("auto", "classic"):
             raise ValueError(f"step_kernel {step_kernel!r}")
         self.step_kernel = step_kernel
+        if reward_mode not in ("sampled", "posterior_mean"):
+            raise ValueError(f"reward_mode {reward_mode!r}")
+        if reward_mode == "posterior_mean" and (self.fixes or reward_path == "table" or step_kernel != "auto"
+                                                or obs_dtype != torch.float32):
+            raise ValueError("reward_mode='posterior_mean' needs faithful semantics, reward_path='gather', "
+                             "step_kernel='auto' and float32 observations")
+        self.reward_mode = reward_mode
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
         if episode_order == "sorted" and seed_mode != "device":
@@ -203,6 +216,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._fr_ptr = self._final_return.data_ptr()
         self._done_bool = self._done.view(torch.bool)
         self._sort_ws = None
+        self._group_ws = None
+        if reward_mode == "posterior_mean":
+            with torch.cuda.device(dev):
+                self._group_ws = torch.empty(self._lib.w2a_group_workspace_bytes(n), dtype=torch.uint8, device=dev)
         nd = np.unique(ct.n_days)
         uniform = len(nd) == 1 and nd[0] > 0
         if episode_order == "sorted":
@@ -256,7 +273,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
         """in-kernel autoreset only when the batch is not in lock step (device seed mode)."""
         self._dev_auto = self.autoreset == "same_step" and self.seed_mode == "device" and not self._lockstep
         self._host_auto = self.autoreset == "same_step" and self.seed_mode == "device" and self._lockstep
+        if self.reward_mode == "posterior_mean" and self._dev_auto:
+            raise ValueError("reward_mode='posterior_mean' cannot run with the in-kernel autoreset (batches that left "
+                             "lock step); use autoreset='disabled' or whole-batch resets")
+        self._pm = self.reward_mode == "posterior_mean"
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
+                            (_ffi.STEP_REWARD_GIVEN if self._pm else 0) |
                             (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
@@ -412,6 +434,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                            None if mask_t is None else mask_t.data_ptr(), obs_ptr, self._stream()),
                        "w2a_reset")
         self._keep = (t, tb, mask_t)  # keep inputs alive until the async launch has consumed them
+        self._regroup()
 
     def _per_env(self, v, i):
         if isinstance(v, (list, tuple, np.ndarray)):
@@ -508,6 +531,14 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 if obs_ptr is not None:
                     _ffi.check(lib.w2a_observe(self._h, obs_ptr, st), "w2a_observe")
         self._steps_in_episode = 0
+        self._regroup()
+
+    def _regroup(self):
+        """posterior_mean: env ids sorted by coefficient column for the grouped GEMM; after EVERY reset."""
+        if self._group_ws is not None:
+            with torch.cuda.device(self.device):
+                _ffi.check(self._lib.w2a_group_by_column(self._h, self._group_ws.data_ptr(), self._group_ws.numel(),
+                                                         self._stream()), "w2a_group_by_column")
 
     # ------------------------------------------------------------------ step
     def step(self, actions):
@@ -521,6 +552,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if _cur_device() != self._dev_index:  # kernels launch on the current device: it must be this env's
             with torch.cuda.device(self.device):
                 return self.step(actions)
+        if self._pm:  # today's reward of every env as the mean over all posterior draws, from the pre-step state
+            rc = self._lib.w2a_posterior_mean_reward(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype],
+                                                     self._rew_ptr, self._stream())
+            if rc != 0:
+                _ffi.check(rc, "w2a_posterior_mean_reward")
         rc = self._w2a_step(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype], self._obs_ptr, self._rew_ptr,
                             self._done_ptr, self._fr_ptr, self._step_flags, self._stream())
         if rc != 0:
@@ -555,6 +591,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
         reset, so consecutive calls evaluate consecutive episodes."""
         if self._needs_reset:
             raise RuntimeError("call reset() before rollout()")
+        if self._pm:
+            raise ValueError("rollout() evaluates the sampled-posterior reward; reward_mode='posterior_mean' is step() only")
         ct = self.ct
         kind = policy.get("kind")
         if kind not in _ffi.POLICY_KINDS:
