@@ -497,6 +497,24 @@ def main():
                 "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
                         "row after each reset"}
             e3.close()
+            # (3) reward_mode="posterior_mean": the reward of every env-step as the mean over all 100 posterior draws,
+            # a grouped fp64-MFMA GEMM per step (the dense "nn_full_medicare reward GEMM" of BASELINE configs[3]/[4])
+            e4 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                                 write_obs=not args.no_obs, reward_mode="posterior_mean")
+            e4.reset(seed=args.seed)
+            timed_steps(e4, pool, 5, torch)
+            kms, _ = timed_steps(e4, pool, 40, torch)
+            us = kms * 1e3 / 40
+            flop_algo = 2.0 * 28 * 2 * ct.n_samples * n          # 28 coefficients x 2 heads x draws, multiply-add
+            flop_mfma = 2.0 * 32 * 2 * 112 * n                   # issued: K padded to 32 slots, draws to 7 x 16
+            out["posterior_mean_reward"] = {
+                "us_per_step": us, "value": n / us * 1e6, "unit": "env-steps/s (k_posterior_mean + k_step64<given>)",
+                "gemm_tflops_algorithmic": flop_algo / (us * 1e-6) / 1e12,
+                "gemm_tflops_issued": flop_mfma / (us * 1e-6) / 1e12,
+                "mfma_peak_tflops_fp64": 78.6,
+                "note": "per step: [envs of a column x 32 slots] x [32 x 2 heads x 100 draws] on v_mfma_f64_16x16x4_f64, "
+                        "f32 sigmoid / gate / mean epilogue; time includes the step kernel that consumes the reward"}
+            e4.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
             procs = min(16, os.cpu_count() or 1)

@@ -242,11 +242,14 @@ typedef struct w2a_policy {
   uint64_t seed;
 } w2a_policy;
 /* Outputs (device, nullable): ret_out f32 [n] rewards summed over the days run by this call, alerts_out i32 [n]
- * alerts issued, attempts_over_budget i32 [n] alerts attempted at budget (silently dropped, Q5), alert_mask
- * u32 [n][mask_words] bit d = alert issued on day d, last_return f32 [n] episode return of envs that finished. */
+ * alerts issued, attempts_over_budget i32 [n] alerts attempted at budget (silently dropped, Q5), alert_mask /
+ * attempt_mask u32 [n][mask_words] bit d = alert issued / attempted on day d (the reference's actual_ and
+ * attempted_alert_buffer, env.py:239,248), last_return f32 [n] episode return of envs that finished,
+ * ret_snapshot f32 [n] the running episode return after the step that leaves t == n_days - 2, the moment the
+ * reference's logging callbacks read the env (callbacks.py:47-48,128-132; untouched if that step is not in this call). */
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
-                int32_t *attempts_over_budget, uint32_t *alert_mask, int32_t mask_words, float *last_return,
-                void *stream);
+                int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
+                float *last_return, float *ret_snapshot, void *stream);
 
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);

@@ -450,24 +450,7 @@ def oracle_rollout(V: "VectorOracle", policy: dict, n_steps: int, seed_stream=No
         live = ~V._finished
         if not live.any():
             break
-        rem = V.budget - V.used
-        kind = policy["kind"]
-        if kind == "never":
-            act = np.zeros(n, np.int64)
-        elif kind == "always":
-            act = np.ones(n, np.int64)
-        elif kind == "bernoulli":
-            u = np.asarray([seed_stream(i, int(V.t[i])) for i in range(n)])
-            act = (u.astype(np.float32) < np.float32(policy["p"])).astype(np.int64)
-        elif kind == "threshold":
-            tt = np.where((V.t > 0) & (policy.get("lag", 1) == 1), V.t - 1, V.t)
-            feat = V.X[V.county_w, V.year_i, tt, policy["col"]]
-            act = (feat.astype(np.float32) > np.float32(policy["threshold"])).astype(np.int64)
-        else:
-            R = policy["table"].shape[1]
-            act = policy["table"][V.t, np.clip(rem, 0, R - 1)].astype(np.int64)
-        if policy.get("require_budget"):
-            act = np.where(rem <= 0, 0, act)
+        act = _policy_actions(V, policy, seed_stream)
         tday = V.t.copy()
         atb = V.used == V.budget
         _, r, done, actual = V.step(act)
@@ -535,3 +518,193 @@ def devrng_reset_tuple(seed, env_gid, episode_no, S, n_years, n_samples, fips_to
         hi = int(1.5 * base + 1)
         b = lo + devrng_bounded(st, DRAW_BUDGET, hi - lo)
     return cw, coef_col, year_i, sample, b
+
+
+# --------------------------------------------------------------------------------------
+# Restatement of the reference's SB3 logging callbacks (src/weather2alert/callbacks.py)
+# --------------------------------------------------------------------------------------
+# The callbacks poll env attributes after every step. They were written against the legacy env and read
+# attributes the current env.py no longer has ("stale"); the restatement runs them against the
+# CURRENT env's semantics with this mapping, each taken from where the legacy env defined it:
+#   env.attempted_alert_buffer  -> same name in env.py:239
+#   env.allowed_alert_buffer    -> env.actual_alert_buffer (env.py:248; legacy _deprecated/env.py:329)
+#   env.penalize                -> "an alert was attempted at budget on this step" (_deprecated/env.py:324-328)
+#   env.cum_reward              -> the running episode return (_deprecated/env.py:343)
+#   env.t, env.n_days           -> same names (env.py:157,165,259: t stops at n_days - 1)
+#   other_data["y"], ["budget"] -> the episode's year and the env's budget (FinalEvalCallback, callbacks.py:129-130)
+# One callback window = one whole episode per env with no reset inside it (evaluation rollouts).
+class _EnvView:
+    """What the callbacks read from one env (names as in callbacks.py)."""
+
+    def __init__(self, n_days, year, budget):
+        self.n_days, self.year, self.budget = int(n_days), int(year), int(budget)
+        self.t = 0
+        self.attempted_alert_buffer, self.allowed_alert_buffer = [], []
+        self.penalize = False
+        self.cum_reward = 0.0
+
+    def after_step(self, attempted, actual, at_budget, reward, t_after):
+        self.attempted_alert_buffer.append(int(attempted))
+        self.allowed_alert_buffer.append(int(actual))
+        self.penalize = bool(attempted == 1 and at_budget)
+        self.cum_reward += float(reward)
+        self.t = int(t_after)
+
+
+class AlertLoggingOracle:
+    """callbacks.py:5-87 (AlertLoggingCallback), line by line, over a list of _EnvView."""
+
+    def __init__(self):  # :8-16
+        self.when_alerted, self.streaks = [], []
+        self.current_streak = None
+        self.last_alert = None
+        self.num_over_budget = self.num_alerts = self.num_steps = 0
+
+    def on_step(self, envs):  # :18-59
+        n_envs = len(envs)
+        if self.current_streak is None:
+            self.last_alert = np.zeros(n_envs, dtype=int)
+            self.current_streak = np.zeros(n_envs, dtype=int)
+            self.rolled_rewards = np.zeros(n_envs, dtype=float)
+            self.a_50 = np.full(n_envs, np.nan)
+            self.a_80 = np.full(n_envs, np.nan)
+            self.a_100 = np.full(n_envs, np.nan)
+        for i, env in enumerate(envs):
+            self.num_steps += 1
+            if env.penalize:
+                self.num_over_budget += 1
+            if env.attempted_alert_buffer:
+                prev_alert = self.last_alert[i]
+                this_alert = env.attempted_alert_buffer[-1]
+                if this_alert:  # alert issued
+                    self.when_alerted.append(env.t)
+                    self.num_alerts += 1
+                    self.current_streak[i] += 1
+                elif prev_alert:  # end streak
+                    self.streaks.append(self.current_streak[i])
+                    self.current_streak[i] = 0
+                self.last_alert[i] = this_alert
+            if env.t == env.n_days - 2:
+                self.rolled_rewards[i] += env.cum_reward
+                s = sum(env.allowed_alert_buffer)
+                if s > 0:
+                    fracs = np.cumsum(env.allowed_alert_buffer) / s
+                    for k in range(0, len(fracs)):
+                        if np.isnan(self.a_100[i]) and fracs[k] == 1:
+                            self.a_100[i] = k
+                        if np.isnan(self.a_80[i]) and fracs[k] >= 0.8:
+                            self.a_80[i] = k
+                        if np.isnan(self.a_50[i]) and fracs[k] >= 0.5:
+                            self.a_50[i] = k
+
+    def on_rollout_end(self):  # :61-77
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)  # nanmean of an all-NaN slice
+            return {
+                "training_rewards": float(np.mean(self.rolled_rewards)),
+                "over_budget_freq": self.num_over_budget / self.num_steps,
+                "alerts_freq": self.num_alerts / self.num_steps,
+                "average_t_alerts": float(np.mean(self.when_alerted)) if self.when_alerted else 0,
+                "stdev_t_alerts": float(np.std(self.when_alerted)) if self.when_alerted else 0,
+                "average_streak": float(np.mean(self.streaks)) if self.streaks else 0,
+                "stdev_streak": float(np.std(self.streaks)) if self.streaks else 0,
+                "alert_t_50%": float(np.nanmean(self.a_50)),
+                "alert_t_80%": float(np.nanmean(self.a_80)),
+                "alert_t_100%": float(np.nanmean(self.a_100)),
+            }
+
+
+CSV_FIELDS = ["year", "alert_budget", "sum_alerts", "reward", "average_t_alerts", "stdev_t_alerts", "average_streak",
+              "stdev_streak", "alerts"]  # callbacks.py:136-146, in the order DictWriter gets them (:153-155)
+
+
+class FinalEvalOracle:
+    """callbacks.py:90-157 (FinalEvalCallback) for one eval env and one episode: the row it appends to its CSV."""
+
+    def __init__(self):  # :104-115
+        self.year = self.budget = self.sum_alerts = self.reward = 0
+        self.alerts, self.when_alerted, self.streaks = [], [], []
+        self.current_streak = self.last_alert = 0
+
+    def on_step(self, env):  # :116-133
+        prev_alert = self.last_alert
+        this_alert = env.allowed_alert_buffer[-1]
+        if this_alert:  # alert issued
+            self.when_alerted.append(env.t)
+            self.current_streak += 1
+        elif prev_alert:  # end streak
+            self.streaks.append(self.current_streak)
+            self.current_streak = 0
+        self.last_alert = this_alert
+        if env.t == env.n_days - 2:
+            self.year = env.year
+            self.budget = env.budget
+            self.alerts = env.allowed_alert_buffer  # the list object: it keeps growing until the episode ends
+            self.sum_alerts = sum(self.alerts)
+            self.reward = env.cum_reward
+
+    def row(self):  # :134-146
+        return {
+            "year": self.year,
+            "alert_budget": self.budget,
+            "sum_alerts": self.sum_alerts,
+            "reward": self.reward,
+            "average_t_alerts": float(np.mean(self.when_alerted)) if self.when_alerted else 0,
+            "stdev_t_alerts": float(np.std(self.when_alerted)) if self.when_alerted else 0,
+            "average_streak": float(np.mean(self.streaks)) if self.streaks else 0,
+            "stdev_streak": float(np.std(self.streaks)) if self.streaks else 0,
+            "alerts": list(self.alerts),
+        }
+
+
+def oracle_rollout_with_callbacks(V: "VectorOracle", policy: dict, seed_stream=None):
+    """One whole episode per env under `policy` (oracle_rollout's policy loop) with both callbacks attached.
+    Returns (AlertLoggingOracle summary, list of FinalEvalOracle rows, per-env returns)."""
+    n = len(V.t)
+    views = [_EnvView(V.n_days[i], V.years[int(V.year_i[i])], V.budget[i]) for i in range(n)]
+    log = AlertLoggingOracle()
+    finals = [FinalEvalOracle() for _ in range(n)]
+    V._finished = np.zeros(n, bool)
+    T = V.X.shape[2]
+    for _ in range(T):
+        live = ~V._finished
+        if not live.any():
+            break
+        tday = V.t.copy()
+        atb = V.used == V.budget
+        acts = _policy_actions(V, policy, seed_stream)
+        _, r, done, actual = V.step(acts)
+        lv = [views[i] for i in range(n) if live[i]]
+        for i in range(n):
+            if live[i]:
+                views[i].after_step(acts[i], actual[i], atb[i], r[i], V.t[i])
+                finals[i].on_step(views[i])
+        log.on_step(lv)
+        V._finished = V._finished | (live & done)
+        del tday
+    return log.on_rollout_end(), [f.row() for f in finals], np.asarray([v.cum_reward for v in views])
+
+
+def _policy_actions(V, policy, seed_stream):
+    n = len(V.t)
+    rem = V.budget - V.used
+    kind = policy["kind"]
+    if kind == "never":
+        act = np.zeros(n, np.int64)
+    elif kind == "always":
+        act = np.ones(n, np.int64)
+    elif kind == "bernoulli":
+        u = np.asarray([seed_stream(i, int(V.t[i])) for i in range(n)])
+        act = (u.astype(np.float32) < np.float32(policy["p"])).astype(np.int64)
+    elif kind == "threshold":
+        tt = np.where((V.t > 0) & (policy.get("lag", 1) == 1), V.t - 1, V.t)
+        feat = V.X[V.county_w, V.year_i, tt, policy["col"]]
+        act = (feat.astype(np.float32) > np.float32(policy["threshold"])).astype(np.int64)
+    else:
+        R = policy["table"].shape[1]
+        act = policy["table"][V.t, np.clip(rem, 0, R - 1)].astype(np.int64)
+    if policy.get("require_budget"):
+        act = np.where(rem <= 0, 0, act)
+    return act

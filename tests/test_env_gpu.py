@@ -1018,3 +1018,59 @@ def test_posterior_mean_lockstep_autoreset_and_guards(dev):
     with pytest.raises(ValueError):  # a masked reset would need the in-kernel autoreset
         e2.reset(seed=1, options={"mask": np.arange(8) < 4})
     e2.close()
+
+
+@pytest.mark.parametrize("kind", ["bernoulli", "threshold", "always"])
+def test_callback_statistics_and_episode_csv(dev, kind, tmp_path):
+    """every statistic of the reference's AlertLoggingCallback (callbacks.py:61-77) and every row
+    of its FinalEvalCallback CSV (:134-157), computed from on-device rollout outputs, against the oracle's literal
+    restatement of the two callbacks polling the oracle env step by step. Ragged episode lengths included."""
+    import csv
+
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=20, years=[2006, 2007, 2008], n_samples=6, seed=37, extra_confounder_fips=3)
+    rng = np.random.default_rng(5)
+    nd = rng.integers(120, 154, size=(20, 3))
+    nd[0, 0] = 153
+    sd.meta["n_days_per_episode"] = nd
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n, gid0 = 257, 77
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", env_gid0=gid0)
+    ep = _random_tuples(ct, n, rng, False)
+    ep["budget"] = rng.integers(0, 9, n)
+    env.reset(options={"episodes": ep})
+    st = _oracle_for_env(env, V)
+    pol = {"bernoulli": dict(kind="bernoulli", p=0.22, seed=5),
+           "threshold": dict(kind="threshold", feature="heat_qi", threshold=0.6),
+           "always": dict(kind="always")}[kind]
+    opol = dict(pol, col=ct.columns.index("heat_qi"))
+    draw = (lambda i, t: O.devrng_policy_uniform(5, gid0 + i, int(st["episode_no"][i]), t)) if kind == "bernoulli" else None
+    out = env.rollout(pol, alert_mask=True)
+    assert out["done"].all()
+    want, rows_o, ret_o = O.oracle_rollout_with_callbacks(V, opol, draw)
+    got = HeatAlertVecEnv.callback_stats(out)
+    assert set(got) == set(want)
+    for k in want:
+        tol = 3e-5 if k == "training_rewards" else 1e-12
+        np.testing.assert_allclose(got[k], want[k], rtol=tol, atol=tol, equal_nan=True, err_msg=k)
+    np.testing.assert_allclose(out["final_return"].cpu().numpy(), ret_o, rtol=3e-5)
+    rows = HeatAlertVecEnv.episode_rows(out)
+    assert len(rows) == len(rows_o) == n
+    for a, b in zip(rows, rows_o):
+        assert list(a) == list(b) == list(O.CSV_FIELDS)
+        for k in O.CSV_FIELDS:
+            if k == "reward":
+                assert abs(a[k] - b[k]) <= 3e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+            elif isinstance(b[k], float):
+                assert abs(a[k] - b[k]) <= 1e-12, (k, a[k], b[k])
+            else:
+                assert a[k] == b[k], (k, a[k], b[k])
+    path = tmp_path / "final_eval.csv"
+    HeatAlertVecEnv.write_episode_csv(str(path), out)
+    with open(path) as f:
+        rd = list(csv.reader(f))
+    assert rd[0] == list(O.CSV_FIELDS) and len(rd) == n + 1
+    assert rd[1][0] == str(rows_o[0]["year"]) and rd[1][-1] == str(rows_o[0]["alerts"])
+    env.close()

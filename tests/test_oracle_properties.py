@@ -78,3 +78,56 @@ def test_vector_oracle_equals_scalar_oracle(small, seed, n, p):
             o, ri, di, _, _ = e.step(int(a[i]))
             assert ri == r[i] and di == done[i] and e.actual_alert_buffer[-1] == actual[i]
             np.testing.assert_array_equal(o, obs[i])
+
+
+def test_episode_csv_fields_are_the_reference_callbacks():
+    """The per-episode CSV (HeatAlertVecEnv.write_episode_csv, oracle CSV_FIELDS) has the field names and order of the
+    reference's FinalEvalCallback (callbacks.py:136-146, written by csv.DictWriter at :151-157). The expected list
+    is committed; when the reference tree is present (build container) it is also read from the source text."""
+    import os
+    import re
+
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd.env import HeatAlertVecEnv
+
+    expect = ["year", "alert_budget", "sum_alerts", "reward", "average_t_alerts", "stdev_t_alerts", "average_streak",
+              "stdev_streak", "alerts"]
+    assert list(O.CSV_FIELDS) == expect == list(HeatAlertVecEnv.CSV_FIELDS)
+    src = "/root/reference/src/weather2alert/callbacks.py"
+    if os.path.exists(src):
+        text = open(src).read()
+        block = text[text.index("self.data.append({"): text.index("# Reset:")]
+        assert re.findall(r'"([a-z_0-9%]+)":', block) == expect
+        logged = re.findall(r'"([a-z_0-9%]+)":', text[text.index("summary = {"): text.index("for k, v in summary.items()")])
+        assert logged == ["training_rewards", "over_budget_freq", "alerts_freq", "average_t_alerts", "stdev_t_alerts",
+                          "average_streak", "stdev_streak", "alert_t_50%", "alert_t_80%", "alert_t_100%"]
+        v, log = O._EnvView(n_days=4, year=2006, budget=1), O.AlertLoggingOracle()
+        v.after_step(1, 1, False, -1.0, 1)
+        log.on_step([v])
+        assert list(log.on_rollout_end()) == logged
+
+
+def test_callback_restatement_on_a_hand_checked_episode():
+    """AlertLoggingOracle / FinalEvalOracle on a 7-day episode worked out by hand from callbacks.py."""
+    from oracle import heatalert_oracle as O
+
+    v = O._EnvView(n_days=7, year=2010, budget=2)
+    log, fin = O.AlertLoggingOracle(), O.FinalEvalOracle()
+    attempted = [1, 1, 1, 0, 1, 0, 0]
+    used = 0
+    for k, a in enumerate(attempted):
+        atb = used == 2
+        actual = 0 if (a and atb) else a
+        used += actual
+        v.after_step(a, actual, atb, -1.0, min(k + 1, 6))
+        fin.on_step(v)
+        log.on_step([v])
+    s = log.on_rollout_end()
+    # attempted alerts on days 0,1,2,4 -> env.t after the step = 1,2,3,5; streaks ended: 3 (days 0-2) and 1 (day 4)
+    assert s["average_t_alerts"] == 2.75 and s["average_streak"] == 2.0 and s["stdev_streak"] == 1.0
+    assert s["alerts_freq"] == 4 / 7 and s["over_budget_freq"] == 2 / 7  # days 2 and 4 were attempted at budget
+    # read at t == 5 (after day 4): granted list [1,1,0,0,0] -> 50 % at index 0, 80 % and 100 % at index 1
+    assert (s["alert_t_50%"], s["alert_t_80%"], s["alert_t_100%"]) == (0.0, 1.0, 1.0) and s["training_rewards"] == -5.0
+    r = fin.row()
+    assert r["year"] == 2010 and r["alert_budget"] == 2 and r["sum_alerts"] == 2 and r["reward"] == -5.0
+    assert r["alerts"] == [1, 1, 0, 0, 0, 0, 0] and r["average_t_alerts"] == 1.5 and r["average_streak"] == 2.0

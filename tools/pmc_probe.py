@@ -24,6 +24,7 @@ p.add_argument("--num-envs", type=int, default=None)
 p.add_argument("--no-obs", action="store_true")
 p.add_argument("--step-kernel", default="auto", choices=["auto", "classic"])
 p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"])
+p.add_argument("--reward-mode", default="sampled", choices=["sampled", "posterior_mean"])
 a = p.parse_args()
 wname, n_default, augment, desc = bench.WORKLOADS[a.workload]
 n = a.num_envs or n_default
@@ -31,7 +32,7 @@ dev = torch.device("cuda:0")
 sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
 env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs,
-                      step_kernel=a.step_kernel, episode_order=a.episode_order)
+                      step_kernel=a.step_kernel, episode_order=a.episode_order, reward_mode=a.reward_mode)
 g = torch.Generator(device=dev).manual_seed(1234)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
 env.reset(seed=0)
@@ -51,7 +52,8 @@ import json  # noqa: E402
 from weather2alert_amd import build as wbuild  # noqa: E402
 
 os.makedirs("gpurun_out", exist_ok=True)
-tag = a.workload + ("_noobs" if a.no_obs else "") + ("_sorted" if a.episode_order == "sorted" else "")
+tag = (a.workload + ("_noobs" if a.no_obs else "") + ("_sorted" if a.episode_order == "sorted" else "")
+       + ("_pm" if a.reward_mode == "posterior_mean" else ""))
 json.dump({"workload": tag, "src_sha": wbuild.source_sha(), "num_envs": n, "steps": a.steps,
            "step_kernel": "k_step64" if a.step_kernel == "auto" else "k_step"},
           open(f"gpurun_out/pmc_probe_{tag}.json", "w"))

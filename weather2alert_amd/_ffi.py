@@ -125,7 +125,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_set_semantics.restype = C.c_int
     lib.w2a_set_semantics.argtypes = [vp, C.c_uint32]
     lib.w2a_rollout.restype = C.c_int
-    lib.w2a_rollout.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.w2a_rollout.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     if lib.w2a_abi_version() != ABI_VERSION:
         raise W2AError(f"libw2a.so ABI {lib.w2a_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib

@@ -418,14 +418,15 @@ int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
 }
 
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
-                int32_t *attempts_over_budget, uint32_t *alert_mask, int32_t mask_words, float *last_return,
-                void *stream) {
+                int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
+                float *last_return, float *ret_snapshot, void *stream) {
   if (!env || !policy) return fail(W2A_ERR_ARG, "w2a_rollout: NULL argument");
   if (n_steps <= 0) return fail(W2A_ERR_ARG, "w2a_rollout: n_steps must be positive");
   if (policy->kind < W2A_POLICY_NEVER || policy->kind > W2A_POLICY_TABLE) return fail(W2A_ERR_ARG, "w2a_rollout: bad policy kind");
   if (policy->kind == W2A_POLICY_TABLE && (!policy->table || policy->table_R <= 0))
     return fail(W2A_ERR_ARG, "w2a_rollout: tabular policy needs table [T][table_R] and table_R > 0");
-  if (alert_mask && mask_words * 32 < env->tb.T) return fail(W2A_ERR_ARG, "w2a_rollout: alert_mask needs ceil(T/32) words per env");
+  if ((alert_mask || attempt_mask) && mask_words * 32 < env->tb.T)
+    return fail(W2A_ERR_ARG, "w2a_rollout: alert_mask / attempt_mask need ceil(T/32) words per env");
   RolloutArgs a;
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.st = env->st; a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
@@ -438,9 +439,11 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     a.pol_slot = slot;
   }
   a.n_steps = n_steps; a.ret_out = ret_out; a.alerts_out = alerts_out; a.attempts_over_budget = attempts_over_budget;
-  a.alert_mask = alert_mask; a.mask_words = mask_words; a.last_return = last_return;
+  a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words; a.last_return = last_return;
+  a.ret_snapshot = ret_snapshot;
   hipStream_t s = (hipStream_t)stream;
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
+  if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_rollout, dim3(grid_for(env->n)), dim3(BLOCK), 0, s, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;

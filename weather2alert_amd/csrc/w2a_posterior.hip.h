@@ -118,22 +118,31 @@ __global__ __launch_bounds__(BLOCK) void k_posterior_mean(const PosteriorArgs a)
         float ga[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) ga[j] = s_ga[w_lo + q + 4 * j];
+        // effectiveness enters only through eff * gate * actual: when no row of this wave has an open gate AND an
+        // alert today (most waves: alerts are budget-limited), its half of the GEMM and its sigmoids are skipped
+        const bool any_eff = __any(ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f || ga[3] != 0.0f);
         for (int nt = 0; nt < tiles; ++nt) {
           pm_double4 accb = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
           const int nn = nt * 16 + (lane & 15);
 #pragma unroll
           for (int ks = 0; ks < ROWF / 4; ++ks) {
             const double bb = (double)sB[0][4 * ks + q][nn];
-            const double be = (double)sB[1][4 * ks + q][nn];
             accb = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bb, accb, 0, 0, 0);
-            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], be, acce, 0, 0, 0);
+          }
+          if (any_eff) {  // wave-uniform
+#pragma unroll
+            for (int ks = 0; ks < ROWF / 4; ++ks) {
+              const double be = (double)sB[1][4 * ks + q][nn];
+              acce = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], be, acce, 0, 0, 0);
+            }
           }
           if (n0 + nn < n_samples) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // D[row = q + 4 j][col = lane & 15]
               const float base = sigmoid_f32((float)accb[j]);
-              const float eff = sigmoid_f32((float)acce[j]);
-              rs[j] += (double)(base * (1.0f - eff * ga[j]));
+              float keep = 1.0f;
+              if (any_eff) keep = 1.0f - sigmoid_f32((float)acce[j]) * ga[j];
+              rs[j] += (double)(base * keep);
             }
           }
         }

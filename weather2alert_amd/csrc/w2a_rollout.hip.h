@@ -23,8 +23,11 @@ struct RolloutArgs {
   int32_t *alerts_out; // [n] alerts actually issued by this call
   int32_t *attempts_over_budget;  // [n] alerts attempted while at budget (nullable)
   uint32_t *alert_mask;           // [n][mask_words] bit d = alert issued on day d (nullable)
+  uint32_t *attempt_mask;         // [n][mask_words] bit d = alert ATTEMPTED on day d, granted or not (nullable)
   int32_t mask_words;
   float *last_return;
+  float *ret_snapshot;            // [n] running episode return after the step that leaves t == n_days - 2 (nullable):
+                                  // what the reference's logging callbacks read (callbacks.py:47-48,128-132)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
@@ -66,6 +69,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   float ret = 0.0f;
   int32_t alerts = 0, over = 0;
   uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
+  uint32_t att_word = 0, att_idx = 0xFFFFFFFFu;
+  float snap = 0.0f;
+  bool snapped = false;
   // feature the policy sees on its first day here: row of day max(t-1, 0) (lagging observation, Q6)
   float feat = 0.0f;
   if (a.pol.kind == W2A_POLICY_THRESHOLD)
@@ -133,6 +139,17 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
         }
         mask_word |= 1u << (t & 31);
       }
+      if (a.attempt_mask && act == 1) {
+        const uint32_t wi = t >> 5;
+        if (wi != att_idx) {
+          if (att_idx != 0xFFFFFFFFu && l == 0 && att_idx < (uint32_t)a.mask_words)
+            a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+          att_idx = wi;
+          att_word = 0;
+        }
+        att_word |= 1u << (t & 31);
+      }
+      if ((done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
       used = used2; hist = hist2; last = actual; atb = atb_s;
       if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
       else { fin = true; active = false; }
@@ -150,6 +167,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
     if (a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
       a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+    if (a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+      a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+    if (a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
   }
 }

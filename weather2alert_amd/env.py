@@ -621,18 +621,28 @@ class HeatAlertVecEnv(_VectorEnvBase):
                "attempts_over_budget": torch.empty(n, dtype=torch.int32, device=dev)}
         words = (ct.T + 31) // 32
         mask = torch.empty((n, words), dtype=torch.int32, device=dev) if alert_mask else None
+        amask = torch.empty((n, words), dtype=torch.int32, device=dev) if alert_mask else None
+        snap = torch.full((n,), float("nan"), dtype=torch.float32, device=dev) if alert_mask else None
+        st0 = self.state() if alert_mask else None
         with torch.cuda.device(dev):
             _ffi.check(self._lib.w2a_rollout(self._h, C.byref(p), steps, out["return"].data_ptr(),
                                              out["alerts"].data_ptr(), out["attempts_over_budget"].data_ptr(),
-                                             None if mask is None else mask.data_ptr(), words, self._fr_ptr,
-                                             self._stream()), "w2a_rollout")
+                                             None if mask is None else mask.data_ptr(),
+                                             None if amask is None else amask.data_ptr(), words, self._fr_ptr,
+                                             None if snap is None else snap.data_ptr(), self._stream()), "w2a_rollout")
         self._keep_pol = keep
         st = self.state()
         out["done"] = st["finished"].bool()  # the terminal step has run (t stops at n_days-1 before AND after it)
-        out["final_return"] = self._final_return.clone()
+        out["final_return"] = self._final_return.clone()  # meaningful where out["done"]
         if mask is not None:
             bits = torch.arange(32, device=dev, dtype=torch.int32)
-            out["alert_days"] = (((mask.unsqueeze(-1) >> bits) & 1).reshape(n, words * 32)[:, : ct.T]).bool()
+            unpack = lambda m: (((m.unsqueeze(-1) >> bits) & 1).reshape(n, words * 32)[:, : ct.T]).bool()  # noqa: E731
+            out["alert_days"] = unpack(mask)      # the reference's actual_alert_buffer (env.py:248), per day
+            out["attempt_days"] = unpack(amask)   # its attempted_alert_buffer (env.py:239)
+            out["return_snapshot"] = snap         # running return when the callbacks read the env (t == n_days - 2)
+            out["n_days"], out["budget"] = st["n_days"], st["budget"]
+            out["first_day"] = st0["t"]           # day index this call started from (0 for whole episodes)
+            out["year"] = torch.as_tensor(ct.years, dtype=torch.int32, device=dev)[st["year_i"].long()]
         if self._host_auto:
             self._steps_in_episode = min(self._steps_in_episode + steps, self._episode_len)
             if self._steps_in_episode >= self._episode_len:
@@ -667,6 +677,98 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 day = ((cum.double() >= need) & (tot > 0)).to(torch.int32).argmax(1)
                 s[f"day_{q}pct_alerts"] = float(day[has].double().mean()) if has.any() else float("nan")
         return s
+
+    @staticmethod
+    def callback_stats(out: dict) -> dict:
+        """What the reference's AlertLoggingCallback logs at the end of a rollout (callbacks.py:61-77), computed on
+        the device from whole-episode rollout outputs (rollout(policy, alert_mask=True) from day 0): same keys, same
+        definitions. The callback polls attributes of the legacy env; they map to the current env as listed in
+        oracle/heatalert_oracle.py (attempted_alert_buffer, actual_alert_buffer for allowed_alert_buffer, "alert
+        attempted at budget" for penalize, the running return for cum_reward). Definitions that follow from its code:
+        streaks and alert days are those of ATTEMPTED alerts (:38-46), a streak is recorded when a no-alert day ends
+        it (an open streak at the end of the window is dropped), alert days are env.t after the step
+        (min(day + 1, n_days - 1)), the 50/80/100 % marks are the first index of the granted-alert list whose
+        cumulative fraction reaches the mark, read when env.t == n_days - 2 (:47-57), as is the logged reward."""
+        att, act = out["attempt_days"], out["alert_days"]
+        n, T = att.shape
+        nd = out["n_days"].long()
+        day = torch.arange(T, device=att.device)
+        live = day[None, :] < nd[:, None]
+        att, act = att & live, act & live
+        num_steps = int(nd.sum())
+        s = {"training_rewards": float(out["return_snapshot"].double().nan_to_num(0.0).mean()),
+             "over_budget_freq": float(out["attempts_over_budget"].sum()) / num_steps,
+             "alerts_freq": float(att.sum()) / num_steps}
+        t_after = torch.minimum(day[None, :] + 1, nd[:, None] - 1).double()
+        w = t_after[att]
+        s["average_t_alerts"] = float(w.mean()) if w.numel() else 0
+        s["stdev_t_alerts"] = float(w.std(unbiased=False)) if w.numel() else 0
+        # streaks of attempted alerts that a no-alert day ended inside the episode: run length at the day before
+        a = att.to(torch.int32)
+        c = a.cumsum(1)
+        zero_c = torch.where(a == 0, c, torch.zeros_like(c)).cummax(1).values  # cumsum at the last 0 so far
+        run = c - zero_c  # consecutive alerts ending at each day
+        ended = (a[:, 1:] == 0) & (a[:, :-1] == 1) & live[:, 1:]
+        lens = run[:, :-1][ended].double()
+        s["average_streak"] = float(lens.mean()) if lens.numel() else 0
+        s["stdev_streak"] = float(lens.std(unbiased=False)) if lens.numel() else 0
+        # 50 / 80 / 100 % marks over the granted alerts of days 0 .. n_days-3 (the list when t == n_days - 2)
+        seen = day[None, :] < (nd[:, None] - 2)
+        g = (act & seen).to(torch.int64)
+        cg = g.cumsum(1)
+        tot = cg[:, -1:]
+        has = tot[:, 0] > 0
+        frac = cg.double() / tot.clamp(min=1).double()
+        for key, q in (("alert_t_50%", 0.5), ("alert_t_80%", 0.8), ("alert_t_100%", 1.0)):
+            hit = ((frac == 1.0) if q == 1.0 else (frac >= q)) & seen
+            first = torch.where(hit, day[None, :], torch.full_like(cg, T)).min(1).values
+            s[key] = float(first[has].double().mean()) if bool(has.any()) else float("nan")
+        return s
+
+    CSV_FIELDS = ("year", "alert_budget", "sum_alerts", "reward", "average_t_alerts", "stdev_t_alerts",
+                  "average_streak", "stdev_streak", "alerts")  # callbacks.py:136-146
+
+    @staticmethod
+    def episode_rows(out: dict) -> list[dict]:
+        """One row per env in the format of the reference's FinalEvalCallback (callbacks.py:116-146) from whole-episode
+        rollout outputs: year, alert_budget, sum_alerts and reward as read when env.t == n_days - 2 (:128-132), alert
+        day / streak statistics over the GRANTED alerts of the whole episode (:118-126), and the granted-alert list."""
+        act = out["alert_days"].cpu().numpy()
+        nd = out["n_days"].cpu().numpy()
+        year, bud = out["year"].cpu().numpy(), out["budget"].cpu().numpy()
+        snap = out["return_snapshot"].cpu().numpy()
+        rows = []
+        for i in range(act.shape[0]):
+            a = act[i, : nd[i]].astype(np.int64)
+            when = np.minimum(np.nonzero(a)[0] + 1, nd[i] - 1)
+            streaks, cur = [], 0
+            for k in range(len(a)):
+                if a[k]:
+                    cur += 1
+                elif k > 0 and a[k - 1]:
+                    streaks.append(cur)
+                    cur = 0
+            read = nd[i] >= 3  # the callback only fills these when it sees t == n_days - 2
+            rows.append({
+                "year": int(year[i]) if read else 0, "alert_budget": int(bud[i]) if read else 0,
+                "sum_alerts": int(a[: nd[i] - 2].sum()) if read else 0, "reward": float(snap[i]) if read else 0,
+                "average_t_alerts": float(np.mean(when)) if len(when) else 0,
+                "stdev_t_alerts": float(np.std(when)) if len(when) else 0,
+                "average_streak": float(np.mean(streaks)) if streaks else 0,
+                "stdev_streak": float(np.std(streaks)) if streaks else 0,
+                "alerts": [int(v) for v in a] if read else []})
+        return rows
+
+    @classmethod
+    def write_episode_csv(cls, path: str, out: dict) -> None:
+        """The per-episode CSV of the reference's FinalEvalCallback (callbacks.py:151-157): header = its field names."""
+        import csv
+
+        with open(path, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(cls.CSV_FIELDS))
+            w.writeheader()
+            for row in cls.episode_rows(out):
+                w.writerow(row)
 
     def _coerce_actions(self, actions):
         if not torch.is_tensor(actions):
