@@ -560,7 +560,7 @@ class AlertLoggingOracle:
         self.last_alert = None
         self.num_over_budget = self.num_alerts = self.num_steps = 0
 
-    def on_step(self, envs):  # :18-59
+    def on_step(self, envs, finished=None):  # :18-59; finished[i]: env i's episode is over, it is not polled
         n_envs = len(envs)
         if self.current_streak is None:
             self.last_alert = np.zeros(n_envs, dtype=int)
@@ -570,6 +570,8 @@ class AlertLoggingOracle:
             self.a_80 = np.full(n_envs, np.nan)
             self.a_100 = np.full(n_envs, np.nan)
         for i, env in enumerate(envs):
+            if finished is not None and finished[i]:
+                continue
             self.num_steps += 1
             if env.penalize:
                 self.num_over_budget += 1
@@ -676,12 +678,11 @@ def oracle_rollout_with_callbacks(V: "VectorOracle", policy: dict, seed_stream=N
         atb = V.used == V.budget
         acts = _policy_actions(V, policy, seed_stream)
         _, r, done, actual = V.step(acts)
-        lv = [views[i] for i in range(n) if live[i]]
         for i in range(n):
             if live[i]:
                 views[i].after_step(acts[i], actual[i], atb[i], r[i], V.t[i])
                 finals[i].on_step(views[i])
-        log.on_step(lv)
+        log.on_step(views, finished=~live)
         V._finished = V._finished | (live & done)
         del tday
     return log.on_rollout_end(), [f.row() for f in finals], np.asarray([v.cum_reward for v in views])
