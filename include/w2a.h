@@ -42,9 +42,7 @@ enum {
 enum {
   W2A_ST_BAD_EPISODE = 1, /* reset tuple out of range (reference: KeyError env.py:127 / ValueError :121) */
   W2A_ST_BAD_ACTION = 2,  /* action not in {0,1} (reference action_space = Discrete(2), env.py:95) */
-  W2A_ST_STEP_AFTER_DONE = 4, /* step() on a finished episode without autoreset */
-  W2A_ST_TABLE_MISMATCH = 8   /* an injected episode pairs a county's weather with another county's
-                                 coefficients: fine for the row-gather path, invalid for W2A_STEP_TABLE */
+  W2A_ST_STEP_AFTER_DONE = 4  /* step() on a finished episode without autoreset */
 };
 
 /* action buffer element types accepted by w2a_step */
@@ -54,9 +52,6 @@ enum { W2A_ACT_I32 = 0, W2A_ACT_I64 = 1, W2A_ACT_U8 = 2 };
 enum {
   W2A_STEP_AUTORESET = 1, /* same-step autoreset with the device RNG (needs w2a_set_autoreset) */
   W2A_STEP_NO_OBS = 2,    /* reward-only: skip the observation write */
-  W2A_STEP_TABLE = 4,     /* logits from the precomputed table L (+ Wendo) instead of the coefficient-row gather;
-                             only for episodes whose coefficient column is the weather county's own (no
-                             similar_climate_counties augmentation) */
   W2A_STEP_CLASSIC = 8,   /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
   W2A_STEP_REWARD_GIVEN = 16 /* `reward` is an INPUT: it already holds today's reward of every env
@@ -95,10 +90,6 @@ typedef struct w2a_tables {
   int32_t n_obs;                  /* observation width (29 with the reference schema)    */
   int32_t obs_slot[W2A_ROW_FLOATS]; /* obs column -> slot, first n_obs entries valid       */
   int32_t slot_heat_qi;           /* slot of the 'heat_qi' feature (informational; the gate reads slot 30) */
-  /* optional logit-table path (all three or none): */
-  const int32_t *weather_to_fips; /* [S_w] county row of X -> its weight column, -1 = none                     */
-  const void *L;                  /* [T][S_w*Y][n_samples] double2 {baseline, gated effectiveness} exogenous logits */
-  const void *Wendo;              /* [S*n_samples][2][4] f32: coefficients of the 4 run-time slots per head    */
   /* optional, for the corrected-semantics flags (w2a_set_semantics): */
   const int32_t *sim_ptr;         /* [S+1] CSR of similar(county) ∩ fips_list, confounders order (W2A_FIX_AUGMENT)     */
   const int32_t *sim_idx;         /* weight-column index of each similar county                                       */
@@ -163,24 +154,13 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
 int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, float *reward, uint8_t *done,
              float *last_return, int flags, void *stream);
 
-/* Dense reward precompute (BASELINE configs[3]/[4], "nn_full_medicare / MFMA path"; no counterpart in the
- * reference, which re-evaluates the 2 x 28-term sums of env.py:207-217 every step): one grouped fp64-MFMA
- * GEMM per county, L[t][county,year][sample] = {sum_k x_k*wb_k, sum_k x_k*we_k (or -inf when heat_qi <= 0.5)}
- * over the table-sourced features + bias, and the compact run-time-slot coefficient rows Wendo. The caller
- * owns both buffers (sizes from the two *_bytes functions) and passes them back in w2a_tables.L / .Wendo. */
-size_t w2a_logit_table_bytes(const w2a_tables *tables);
-size_t w2a_wendo_bytes(const w2a_tables *tables);
-int w2a_build_logit_table(const w2a_tables *tables, void *L, size_t L_bytes, void *Wendo, size_t Wendo_bytes,
-                          void *stream);
-
 /* episode_order="sorted" (no reference counterpart; opt-in): after a reset, relabel the envs so that env
- * indices follow the coefficient row (by_weather_row = 0, row-gather path) or the (county, year, draw) logit
- * row (by_weather_row = 1, table path). The multiset of episodes is unchanged -- only which env index holds
+ * indices follow the coefficient row. The multiset of episodes is unchanged -- only which env index holds
  * which episode -- but neighbouring envs now share table lines, which the step kernel's gathers turn into
  * L2 hits. The whole per-env record moves (episode tuple, budget, sticky budget, episode number).
  * workspace: caller-owned, w2a_sort_workspace_bytes(num_envs) bytes, 256-B aligned. */
 size_t w2a_sort_workspace_bytes(int64_t num_envs);
-int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream);
+int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* reward_mode = "posterior_mean" (the legacy env's eval mode, _deprecated/env.py:332-342: `posterior_indices =
  * np.arange(n_posterior_samples) if eval_mode`, `np.mean([_get_reward(i, ...)])`, on today's reward form

@@ -36,23 +36,21 @@ def test_host_only_entry_points(lib):
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
-    assert b >= 256 + 32 * n and b % 256 == 0
+    assert b >= 256 + 40 * n and b % 256 == 0
     # NULL / bad arguments are rejected on the host with a message, nothing is launched
     h = C.c_void_p()
     assert lib.w2a_create(None, 10, 0, None, 0, None, C.byref(h)) == -1
     assert b"NULL" in lib.w2a_last_error()
     assert lib.w2a_step(None, None, 0, None, None, None, None, 0, None) == -1
     assert lib.w2a_reset_device_rng(None, 0, -1, 0, -1, 0, 1, 1, None, None, None) == -1
-    t = _ffi.Tables()
-    t.T, t.S_w, t.Y, t.S, t.n_samples = 153, 746, 11, 746, 100
-    assert lib.w2a_logit_table_bytes(C.byref(t)) == 153 * 746 * 11 * 100 * 16
-    assert lib.w2a_wendo_bytes(C.byref(t)) == 746 * 100 * 32
-    assert lib.w2a_build_logit_table(C.byref(t), None, 0, None, 0, None) == -1
+    assert lib.w2a_group_workspace_bytes(0) == 0 and lib.w2a_group_workspace_bytes(1000) >= 4 * 4 * 1000
+    assert lib.w2a_group_by_column(None, None, 0, None) == -1
+    assert lib.w2a_posterior_mean_reward(None, None, 0, None, None) == -1
 
 
 def test_ffi_struct_layout_matches_header():
-    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 5 pointers + 1 int32 (+4 pad), naturally aligned
-    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 5 * 8 + 8
+    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 2 pointers + 1 int32 (+4 pad), naturally aligned
+    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 2 * 8 + 8
     assert C.sizeof(_ffi.StateView) == 16 * 8
 
 

@@ -118,10 +118,10 @@ def _random_tuples(ct, n, rng, augment):
                 sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 12, n))
 
 
-@pytest.mark.parametrize("n,augment,adversarial,path", [
-    (4099, False, False, "gather"), (65536, True, False, "gather"), (8192, False, True, "gather"),
-    (4099, False, False, "table"), (8192, False, True, "table")])
-def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, path):
+@pytest.mark.parametrize("n,augment,adversarial,kernel", [
+    (4099, False, False, "auto"), (65536, True, False, "auto"), (8192, False, True, "auto"),
+    (4099, False, False, "classic"), (8192, False, True, "classic")])
+def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, kernel):
     """HIP path vs the float64 vector oracle over a full 153-step episode on a synthetic data set
     (64 counties x 4 years, 16 posterior draws). 'adversarial' uses unscaled N(0,1) coefficients
     (logit terms up to ~150 with cancellation) to show the fp64 accumulation holds the 1e-5 bar."""
@@ -134,7 +134,7 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, path):
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
     rng = np.random.default_rng(n)
     ep = _random_tuples(ct, n, rng, augment)
-    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_path=path)
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel=kernel)
     obs, _ = env.reset(options={"episodes": ep})
     assert env.check_status() == 0
     obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
@@ -155,7 +155,7 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, path):
     np.testing.assert_array_equal(st["t"], V.t)
     np.testing.assert_array_equal(st["hist14"], (V.hist * (1 << np.arange(13, -1, -1))).sum(axis=1))
     np.testing.assert_array_equal(st["budget"] - st["used"], V.budget - V.used)
-    print(f"n={n} adversarial={adversarial} path={path}: max |reward - oracle| = {worst:.3e}")
+    print(f"n={n} adversarial={adversarial} kernel={kernel}: max |reward - oracle| = {worst:.3e}")
     env.close()
 
 
@@ -201,52 +201,15 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     old.close()
 
 
-def test_logit_table_matches_float64_contraction(dev):
-    """The grouped fp64-MFMA precompute (k_logit_table) against a NumPy float64 einsum: every
-    (day, county, year, posterior draw, head), gate folded in as -inf; and the packed run-time-slot rows."""
-    from weather2alert_amd.tables import DeviceTables
-
-    sd = synth.make_synth("linear", n_fips=20, n_counties_weather=13, years=[2006, 2007, 2008], n_samples=11, seed=21,
-                          weight_scale=None, weight_sigma=1.0)
-    ct = tables.compile_from_synth(sd)
-    dt = DeviceTables(ct, dev).build_logit_table(timed=True)
-    L = dt.L.cpu().numpy()  # [T, S_w*Y, n_samples, 2]
-    X = ct.X.astype(np.float64)  # [T, R, 32]
-    W = ct.W.reshape(ct.S, ct.n_samples, 2, 32).astype(np.float64)
-    w2f = dt.weather_to_fips.cpu().numpy()
-    tab = [k for k in range(32) if k not in (24, 25, 26, 27)]
-    assert (w2f >= 0).all() and len(set(w2f.tolist())) == ct.S_w
-    for c in range(ct.S_w):
-        rows = slice(c * ct.Y, (c + 1) * ct.Y)
-        ref = np.einsum("trk,shk->trsh", X[:, rows][:, :, tab], W[w2f[c]][:, :, tab])
-        closed = ~(ct.X[:, rows, ct.slot_of["heat_qi"]] > 0.5)
-        ref[..., 1][closed] = -np.inf
-        got = L[:, rows]
-        fin = np.isfinite(ref)
-        assert np.array_equal(np.isfinite(got), fin)
-        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-13, atol=1e-13)
-    Wendo = dt.Wendo.cpu().numpy()
-    np.testing.assert_array_equal(Wendo, ct.W[:, :, 24:28])
-    assert (~np.isfinite(L[..., 1])).mean() > 0.2  # roughly half the gates are closed
-    print("logit-table build ms:", dt.logit_build_ms)
-
-
-def test_table_path_rejects_augmentation(dev, mini):
+def test_removed_table_path_is_refused(dev, mini):
     from weather2alert_amd import HeatAlertVecEnv
 
     d, meta, ct, dt, _ = mini
-    with pytest.raises(ValueError):
-        HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", similar_climate_counties=True)
-    env = HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", autoreset="disabled")
-    with pytest.raises(ValueError):
-        env.reset(seed=0, options={"similar_climate_counties": True})
-    # an injected tuple that pairs county 0's weather with county 1's coefficients is flagged
-    env.reset(options={"episodes": dict(county_w=0, year_i=0, coef_col=(int(dt.weather_to_fips[0]) + 1) % ct.S,
-                                        sample=0)})
-    with pytest.raises(ValueError):
-        env.check_status()
-    assert HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto").reward_path == "gather"
-    env.close()
+    with pytest.raises(ValueError, match="removed"):
+        HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table")
+    e = HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="auto")
+    assert e.reward_path == "gather"
+    e.close()
 
 
 def test_device_rng_reset_matches_restatement(dev):
@@ -297,8 +260,8 @@ def test_device_rng_reset_matches_restatement(dev):
     env.close()
 
 
-@pytest.mark.parametrize("path,lockstep", [("gather", True), ("gather", False), ("table", True), ("table", False)])
-def test_same_step_autoreset_and_shard_invariance(dev, path, lockstep):
+@pytest.mark.parametrize("lockstep", [True, False])
+def test_same_step_autoreset_and_shard_invariance(dev, lockstep):
     """Lock-step autoreset on the device: after 153 steps every env restarts inside the same
     call; final returns are reported; and two half-size shards keyed by global env id give the
     same trajectories as one full-size env (multi-GPU correctness by construction)."""
@@ -309,11 +272,11 @@ def test_same_step_autoreset_and_shard_invariance(dev, path, lockstep):
     n = 2048 + 40
     # `full` is driven as requested; the shards use the other autoreset implementation (host-counted lock step
     # vs in-kernel), so the comparison also proves the two implementations draw identical episodes
-    full = HeatAlertVecEnv(n, tables=ct, device=dev, reward_path=path, lockstep=lockstep)
+    full = HeatAlertVecEnv(n, tables=ct, device=dev, lockstep=lockstep)
     assert full._lockstep == lockstep
     h = n // 2
-    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0, reward_path=path, lockstep=not lockstep),
-             HeatAlertVecEnv(n - h, tables=ct, device=dev, env_gid0=h, reward_path="gather", lockstep=lockstep)]
+    parts = [HeatAlertVecEnv(h, tables=ct, device=dev, env_gid0=0, lockstep=not lockstep),
+             HeatAlertVecEnv(n - h, tables=ct, device=dev, env_gid0=h, lockstep=lockstep)]
     o_full, _ = full.reset(seed=77)
     o_parts = [p.reset(seed=77)[0] for p in parts]
     assert torch.equal(o_full, torch.cat(o_parts))
@@ -325,10 +288,9 @@ def test_same_step_autoreset_and_shard_invariance(dev, path, lockstep):
         outs = [p.step(a[s].to(dev)) for p, s in zip(parts, (slice(0, h), slice(h, n)))]
         assert torch.equal(o, torch.cat([x[0] for x in outs]))
         r_parts = torch.cat([x[1] for x in outs])
-        if path == "gather":  # second shard: same kernel variant as `full` -> bit-identical rewards
-            assert torch.equal(r[h:], outs[1][1])
+        assert torch.equal(r[h:], outs[1][1])  # second shard: same kernel variant as `full` -> bit-identical rewards
         # first shard: the other autoreset implementation, i.e. the other step kernel (different order of the fp64
-        # additions); table vs gather agree to f32 rounding of the sigmoid input
+        # additions)
         assert torch.allclose(r, r_parts, rtol=0, atol=2e-6)
         assert torch.equal(d, torch.cat([x[2] for x in outs]))
         if t < 153:
@@ -425,16 +387,15 @@ def test_masked_reset_bad_inputs_and_reward_only(dev, mini):
     b.close()
 
 
-@pytest.mark.parametrize("path", ["gather", "table"])
-def test_sorted_episode_order_is_a_relabelling(dev, path):
+def test_sorted_episode_order_is_a_relabelling(dev):
     """episode_order='sorted': same multiset of episodes as the iid order for the same seed, env indices
     follow the table rows, stepping (incl. the host-driven lock-step autoreset) matches the oracle."""
     from weather2alert_amd import HeatAlertVecEnv
 
     sd = synth.make_synth("linear", n_fips=48, years=[2006, 2007, 2008], n_samples=12, seed=9, extra_confounder_fips=4)
     ct = tables.compile_from_synth(sd)
-    n, aug = 3000 + 17, path == "gather"
-    kw = dict(tables=ct, device=dev, reward_path=path, similar_climate_counties=aug)
+    n = 3000 + 17
+    kw = dict(tables=ct, device=dev, similar_climate_counties=True)
     iid = HeatAlertVecEnv(n, **kw)
     srt = HeatAlertVecEnv(n, episode_order="sorted", **kw)
     iid.reset(seed=5)
@@ -443,10 +404,7 @@ def test_sorted_episode_order_is_a_relabelling(dev, path):
     a = np.stack([iid.state()[k].cpu().numpy() for k in keys], 1)
     b = np.stack([srt.state()[k].cpu().numpy() for k in keys], 1)
     assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])  # same multiset of records
-    if path == "gather":
-        k = (b[:, 2].astype(np.int64) << 12 | b[:, 3]) << 32 | (b[:, 0] * ct.Y + b[:, 1])
-    else:
-        k = ((b[:, 0] * ct.Y + b[:, 1]).astype(np.int64) << 12) | b[:, 3]
+    k = (b[:, 2].astype(np.int64) << 12 | b[:, 3]) << 32 | (b[:, 0] * ct.Y + b[:, 1])
     assert (np.diff(k) >= 0).all() and len(np.unique(k)) > n // 4
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
     rng = np.random.default_rng(0)
@@ -711,8 +669,6 @@ def test_corrected_augmentation_and_budget(dev):
         e0.reset(seed=1, options={"location": ct.fips_list[3]})
     e0.close()
     with pytest.raises(ValueError):
-        HeatAlertVecEnv(8, tables=ct, device=dev, reward_path="table", fixes={"alert_2wks"})
-    with pytest.raises(ValueError):
         HeatAlertVecEnv(8, tables=ct, device=dev, fixes={"nonsense"})
     e = HeatAlertVecEnv(8, tables=ct, device=dev, faithful=False)
     assert e.fixes == {"alert_2wks", "lag", "penalty", "obs", "augment", "budget"}
@@ -907,8 +863,8 @@ def test_other_schema_parity(dev):
     county = rng.integers(0, ct.S, n)
     ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
               sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 9, n))
-    for path in ("gather", "table"):
-        env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_path=path)
+    for kernel in ("auto", "classic"):
+        env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel=kernel)
         obs, _ = env.reset(options={"episodes": ep})
         assert obs.shape == (n, 28)
         obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])

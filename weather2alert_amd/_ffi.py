@@ -9,9 +9,9 @@ from . import build as _build
 ROW_FLOATS = 32
 
 OK = 0
-ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_TABLE_MISMATCH = 1, 2, 4, 8
+ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_TABLE, STEP_CLASSIC, STEP_REWARD_GIVEN = 1, 2, 4, 8, 16
+STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN = 1, 2, 8, 16
 ABI_VERSION = 4
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
@@ -20,7 +20,6 @@ BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
-    "w2a_logit_table_bytes", "w2a_wendo_bytes", "w2a_build_logit_table",
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_set_semantics",
     "w2a_set_obs_format", "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
 ]
@@ -40,7 +39,6 @@ class Tables(C.Structure):
         ("fips_to_weather", C.c_void_p), ("sim_cnt", C.c_void_p),
         ("T", C.c_int32), ("S_w", C.c_int32), ("Y", C.c_int32), ("S", C.c_int32), ("n_samples", C.c_int32),
         ("n_obs", C.c_int32), ("obs_slot", C.c_int32 * ROW_FLOATS), ("slot_heat_qi", C.c_int32),
-        ("weather_to_fips", C.c_void_p), ("L", C.c_void_p), ("Wendo", C.c_void_p),
         ("sim_ptr", C.c_void_p), ("sim_idx", C.c_void_p), ("slot_alerts_2wks", C.c_int32),
     ]
 
@@ -102,16 +100,10 @@ def load(build_if_missing: bool = True):
     lib.w2a_get_state.argtypes = [vp, C.POINTER(StateView), vp]
     lib.w2a_read_status.restype = C.c_int
     lib.w2a_read_status.argtypes = [vp, C.POINTER(i32), vp]
-    lib.w2a_logit_table_bytes.restype = C.c_size_t
-    lib.w2a_logit_table_bytes.argtypes = [C.POINTER(Tables)]
-    lib.w2a_wendo_bytes.restype = C.c_size_t
-    lib.w2a_wendo_bytes.argtypes = [C.POINTER(Tables)]
-    lib.w2a_build_logit_table.restype = C.c_int
-    lib.w2a_build_logit_table.argtypes = [C.POINTER(Tables), vp, C.c_size_t, vp, C.c_size_t, vp]
     lib.w2a_sort_workspace_bytes.restype = C.c_size_t
     lib.w2a_sort_workspace_bytes.argtypes = [i64]
     lib.w2a_sort_episodes.restype = C.c_int
-    lib.w2a_sort_episodes.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
+    lib.w2a_sort_episodes.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_group_workspace_bytes.restype = C.c_size_t
     lib.w2a_group_workspace_bytes.argtypes = [i64]
     lib.w2a_group_by_column.restype = C.c_int

@@ -49,7 +49,7 @@ __device__ __forceinline__ float4 ld_w(const float4 *p) {
 // ----------------------------------------------------------------------------------------
 // packed state
 // ----------------------------------------------------------------------------------------
-// Three arrays (40 B per env; a step streams 24 B in and 12 B out) + one for the logit-table path:
+// Three arrays (40 B per env; a step streams 24 B in and 12 B out):
 //   cold  (uint4, reset-time record, not read by the plain step kernel):
 //           x = ep_row (county_w*Y + year_i), y = coef_col << 12 | sample (n_samples <= 4096),
 //           z = sticky budget (int, -1 unset), w = episode number
@@ -58,16 +58,12 @@ __device__ __forceinline__ float4 ld_w(const float4 *p) {
 //           dyn0: t[0:10) used[10:20) streak[20:30) last_actual[30] at_budget[31]
 //           dyn1: hist14[0:14) n_days[16:26) finished[31]
 //           episode return (f32 bits)
-//   rtw   (2 x float4, table path only, read-only while an episode runs): the env's run-time-slot coefficients
-//           {w_lag1, w_streak, w_rem, w_a2w} per head, copied from Wendo at reset so that the step kernel
-//           streams them (32 B coalesced) instead of gathering a third random line per env
 // Kernels work on the logical views  cold = {ep_row, ep_w, sticky, episode_no},  hot = {dyn0, dyn1, ret, budget}.
 struct u3 { uint32_t a, b, c; };
 struct StateArrays {
   uint4 *cold;
   u3 *hot3;
   u3 *stepc;
-  float4 *rtw;
 };
 // per-step view: hot complete, cold.x/.y valid (cold.z/.w = 0: load_cold() when the sticky budget / episode
 // number are needed)
@@ -82,18 +78,12 @@ __device__ __forceinline__ void store_hot(const StateArrays &s, uint32_t e, cons
   u3 h; h.a = hot.x; h.b = hot.y; h.c = hot.z;
   s.hot3[e] = h;
 }
-// a new episode: all arrays. wendo/n_samples: the handle's Wendo table (NULL without the logit-table path)
-__device__ __forceinline__ void store_episode(const StateArrays &s, uint32_t e, const uint4 cold, const uint4 hot,
-                                              const float4 *wendo, int32_t n_samples) {
+// a new episode: all arrays
+__device__ __forceinline__ void store_episode(const StateArrays &s, uint32_t e, const uint4 cold, const uint4 hot) {
   s.cold[e] = cold;
   u3 c; c.a = hot.w; c.b = cold.x; c.c = cold.y;
   s.stepc[e] = c;
   store_hot(s, e, hot);
-  if (wendo) {
-    const uint32_t wrow = (cold.y >> 12) * (uint32_t)n_samples + (cold.y & 4095u);
-    s.rtw[2 * e] = wendo[2 * wrow];
-    s.rtw[2 * e + 1] = wendo[2 * wrow + 1];
-  }
 }
 #define D0_T(d) ((d) & 1023u)
 #define D0_USED(d) (((d) >> 10) & 1023u)
@@ -119,9 +109,6 @@ struct DevTables {
   const float4 *W;
   const int32_t *fips_to_weather;
   const int32_t *sim_cnt;
-  const int32_t *weather_to_fips;  // [S_w] inverse of fips_to_weather (-1: county has no coefficients); nullable
-  const double2 *L;                // [T][S_w*Y][n_samples] {baseline, gated effectiveness} exogenous logits; nullable
-  const float4 *Wendo;             // [S*n_samples][2] run-time-slot coefficients (slots 24..27) per head; nullable
   const int32_t *sim_ptr;          // [S+1] CSR of similar(county) ∩ fips_list (only for W2A_FIX_AUGMENT); nullable
   const int32_t *sim_idx;
   int32_t T, S_w, Y, S, n_samples, n_obs;

@@ -20,8 +20,9 @@
 //     broadcast loads; the hot word is written back as whole 128-B lines per wave;
 //   * the effectiveness coefficient row is fetched only for envs that issue an alert today
 //     (it enters the reward through eff * actual, env.py:221): half the gather traffic;
-//   * workgroup -> env-tile mapping is XCD-aware (logical_block); the dense reward precompute
-//     (k_logit_table) is the only MFMA user (fp64 16x16x4).
+//   * workgroup -> env-tile mapping is XCD-aware (logical_block); k_step64 (w2a_step64.hip.h) is the lean
+//     64-envs-per-wave form of the same step for plain lock-step batches; the posterior-mean reward GEMM
+//     (k_posterior_mean) is the only MFMA user (fp64 16x16x4).
 //
 // No fallback path exists: without this library (or without a ROCm device) constructing an env raises.
 
@@ -38,7 +39,6 @@
 #include "w2a_step64.hip.h"
 #include "w2a_posterior.hip.h"
 #include "w2a_reset.hip.h"
-#include "w2a_logit_table.hip.h"
 #include "w2a_rollout.hip.h"
 #include "w2a_sort.hip.h"
 
@@ -58,7 +58,7 @@ const char *w2a_last_error(void) { return g_err; }
 
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
-  size_t b = HDR_BYTES + (size_t)num_envs * 72 + 16;  // cold 16 + hot3 12 + stepc 12 + (16-B alignment) + rtw 32
+  size_t b = HDR_BYTES + (size_t)num_envs * 40 + 16;  // cold 16 + hot3 12 + stepc 12
   return (b + 255) & ~(size_t)255;
 }
 
@@ -78,10 +78,6 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
     return fail(W2A_ERR_SCHEMA, "w2a_create: tables / env count exceed the 32-bit offset range of the kernels");
   if (t->n_samples > (1 << SAMPLE_BITS) || t->S >= (1 << (32 - SAMPLE_BITS)))
     return fail(W2A_ERR_SCHEMA, "w2a_create: need n_samples <= 4096 and S < 2^20");
-  if ((t->L != nullptr) != (t->Wendo != nullptr) || (t->L && !t->weather_to_fips))
-    return fail(W2A_ERR_ARG, "w2a_create: L, Wendo and weather_to_fips must be given together");
-  if (((uintptr_t)t->L & 15) || ((uintptr_t)t->Wendo & 15))
-    return fail(W2A_ERR_STATE, "w2a_create: L and Wendo must be 16-B aligned");
   if (t->n_obs <= 0 || t->n_obs > W2A_ROW_FLOATS - 1)
     return fail(W2A_ERR_SCHEMA, "w2a_create: n_obs must be in 1..31 (the observation tile keeps one scratch column)");
   if (state_bytes < w2a_state_bytes(num_envs)) return fail(W2A_ERR_STATE, "w2a_create: state buffer too small");
@@ -101,13 +97,10 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->tb.W = reinterpret_cast<const float4 *>(t->W);
   h->tb.fips_to_weather = t->fips_to_weather;
   h->tb.sim_cnt = t->sim_cnt;
-  h->tb.weather_to_fips = t->weather_to_fips;
   h->tb.sim_ptr = t->sim_ptr;
   h->tb.sim_idx = t->sim_idx;
   h->tb.slot_hist2w = t->slot_alerts_2wks;
   h->tb.fixes = 0;
-  h->tb.L = reinterpret_cast<const double2 *>(t->L);
-  h->tb.Wendo = reinterpret_cast<const float4 *>(t->Wendo);
   h->tb.T = t->T; h->tb.S_w = t->S_w; h->tb.Y = t->Y; h->tb.S = t->S; h->tb.n_samples = t->n_samples;
   h->tb.n_obs = t->n_obs;
   h->n = num_envs;
@@ -116,8 +109,6 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
   h->st.hot3 = reinterpret_cast<u3 *>(h->st.cold + num_envs);
   h->st.stepc = h->st.hot3 + num_envs;
-  // 16-B aligned: HDR (256) + 40*N bytes, N*40 % 16 == 0 needs N even -> round the offset up instead
-  h->st.rtw = t->Wendo ? reinterpret_cast<float4 *>(((uintptr_t)(h->st.stepc + num_envs) + 15) & ~(uintptr_t)15) : nullptr;
   h->status = status;
   h->has_autoreset = 0;
   h->obs_f16 = 0;
@@ -199,14 +190,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_step: bad action_dtype");
   const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
   const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
-  const bool table = (flags & W2A_STEP_TABLE) != 0;
   const bool given = (flags & W2A_STEP_REWARD_GIVEN) != 0;
-  if (given && (autoreset || table || env->tb.fixes || env->obs_f16 || (flags & W2A_STEP_CLASSIC)))
+  if (given && (autoreset || env->tb.fixes || env->obs_f16 || (flags & W2A_STEP_CLASSIC)))
     return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is served by the 64-envs-per-wave kernel only (no in-kernel "
-                             "autoreset, no logit table, no corrected-semantics flags, f32 observations)");
-  if (table && !env->tb.L) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_TABLE needs tables with L/Wendo (w2a_build_logit_table)");
-  if (table && autoreset && env->autoreset.augment)
-    return fail(W2A_ERR_ARG, "w2a_step: the logit-table path cannot serve similar_climate_counties episodes");
+                             "autoreset, no corrected-semantics flags, f32 observations)");
   if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
   if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
@@ -221,7 +208,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
 #if W2A_F64_SIGMOID
   if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
 #else
-  if (!autoreset && !table && !env->tb.fixes && !env->obs_f16 && !(flags & W2A_STEP_CLASSIC)) {
+  if (!autoreset && !env->tb.fixes && !env->obs_f16 && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
     const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
@@ -236,60 +223,16 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     return W2A_OK;
   }
 #endif
-#define W2A_LAUNCH(AR, OB, TB) \
-  do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, TB, true>), grid, block, 0, s, a); \
-       else hipLaunchKernelGGL((k_step<AR, OB, TB, false>), grid, block, 0, s, a); } while (0)
-  const int variant = (autoreset ? 4 : 0) | (no_obs ? 0 : 2) | (table ? 1 : 0);
-  switch (variant) {
-    case 0: W2A_LAUNCH(false, false, false); break;
-    case 1: W2A_LAUNCH(false, false, true); break;
-    case 2: W2A_LAUNCH(false, true, false); break;
-    case 3: W2A_LAUNCH(false, true, true); break;
-    case 4: W2A_LAUNCH(true, false, false); break;
-    case 5: W2A_LAUNCH(true, false, true); break;
-    case 6: W2A_LAUNCH(true, true, false); break;
-    default: W2A_LAUNCH(true, true, true); break;
-  }
+#define W2A_LAUNCH(AR, OB) \
+  do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, true>), grid, block, 0, s, a); \
+       else hipLaunchKernelGGL((k_step<AR, OB, false>), grid, block, 0, s, a); } while (0)
+  if (autoreset) { if (no_obs) W2A_LAUNCH(true, false); else W2A_LAUNCH(true, true); }
+  else { if (no_obs) W2A_LAUNCH(false, false); else W2A_LAUNCH(false, true); }
 #undef W2A_LAUNCH
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }
 
-
-size_t w2a_logit_table_bytes(const w2a_tables *t) {
-  if (!t || t->T <= 0 || t->S_w <= 0 || t->Y <= 0 || t->n_samples <= 0) return 0;
-  return (size_t)t->T * t->S_w * t->Y * t->n_samples * sizeof(double2);
-}
-
-size_t w2a_wendo_bytes(const w2a_tables *t) {
-  if (!t || t->S <= 0 || t->n_samples <= 0) return 0;
-  return (size_t)t->S * t->n_samples * 2 * sizeof(float4);
-}
-
-int w2a_build_logit_table(const w2a_tables *t, void *L, size_t L_bytes, void *Wendo, size_t Wendo_bytes, void *stream) {
-  if (!t || !L || !Wendo) return fail(W2A_ERR_ARG, "w2a_build_logit_table: NULL argument");
-  if (!t->X || !t->W || !t->weather_to_fips) return fail(W2A_ERR_ARG, "w2a_build_logit_table: X, W and weather_to_fips are required");
-  if (L_bytes < w2a_logit_table_bytes(t) || Wendo_bytes < w2a_wendo_bytes(t))
-    return fail(W2A_ERR_STATE, "w2a_build_logit_table: output buffer too small");
-  if (((uintptr_t)L & 15) || ((uintptr_t)Wendo & 15)) return fail(W2A_ERR_STATE, "w2a_build_logit_table: buffers must be 16-B aligned");
-  if ((int64_t)t->T * t->S_w * t->Y > 0x7FFFFFFFll) return fail(W2A_ERR_SCHEMA, "w2a_build_logit_table: table too large");
-  LogitArgs a;
-  memset(&a, 0, sizeof(a));
-  a.tb.X = reinterpret_cast<const float4 *>(t->X);
-  a.tb.W = reinterpret_cast<const float4 *>(t->W);
-  a.tb.weather_to_fips = t->weather_to_fips;
-  a.tb.T = t->T; a.tb.S_w = t->S_w; a.tb.Y = t->Y; a.tb.S = t->S; a.tb.n_samples = t->n_samples;
-  a.L = reinterpret_cast<double *>(L);
-  a.msplit = 4;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_logit_table, dim3((unsigned)t->S_w, (unsigned)a.msplit), dim3(BLOCK), 0, s, a);
-  HIP_TRY(hipGetLastError());
-  const int64_t rows = (int64_t)t->S * t->n_samples;
-  hipLaunchKernelGGL(k_pack_wendo, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
-                     reinterpret_cast<const float4 *>(t->W), reinterpret_cast<float4 *>(Wendo), rows);
-  HIP_TRY(hipGetLastError());
-  return W2A_OK;
-}
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t cub_sort_bytes(int64_t n) {
@@ -302,11 +245,11 @@ static size_t cub_sort_bytes(int64_t n) {
 size_t w2a_sort_workspace_bytes(int64_t num_envs) {
   if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
   size_t n = (size_t)num_envs;
-  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 + align256(32 * n) +
+  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 +
          align256(cub_sort_bytes(num_envs));
 }
 
-int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t workspace_bytes, void *stream) {
+int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_sort_episodes: NULL argument");
   if (workspace_bytes < w2a_sort_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace must be 256-B aligned");
@@ -319,21 +262,19 @@ int w2a_sort_episodes(w2a_env *env, int by_weather_row, void *workspace, size_t 
   uint4 *cold_t = (uint4 *)p;      p += align256(16 * n);
   u3 *hot_t = (u3 *)p;             p += align256(12 * n);
   u3 *stepc_t = (u3 *)p;           p += align256(12 * n);
-  float4 *rtw_t = (float4 *)p;     p += align256(32 * n);
   size_t cub_bytes = cub_sort_bytes(env->n);
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n, by_weather_row);
+  hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
   StateArrays tmp;
-  tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t; tmp.rtw = env->st.rtw ? rtw_t : nullptr;
+  tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t;
   hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->st, i_out, tmp, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
-  if (env->st.rtw) HIP_TRY(hipMemcpyAsync(env->st.rtw, rtw_t, 32 * n, hipMemcpyDeviceToDevice, s));
   return W2A_OK;
 }
 
@@ -408,9 +349,6 @@ int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
   if (fixes & ~(uint32_t)W2A_FIX_ALL) return fail(W2A_ERR_ARG, "w2a_set_semantics: unknown W2A_FIX_* bit");
   if ((fixes & W2A_FIX_AUGMENT) && (!env->tb.sim_ptr || !env->tb.sim_idx))
     return fail(W2A_ERR_ARG, "w2a_set_semantics: W2A_FIX_AUGMENT needs sim_ptr/sim_idx in the tables");
-  if ((fixes & W2A_FIX_ALERTS_2WKS) && env->tb.L)
-    return fail(W2A_ERR_ARG, "w2a_set_semantics: W2A_FIX_ALERTS_2WKS moves a coefficient out of the precomputed logit "
-                             "table; create the handle without L/Wendo (row-gather path)");
   if ((fixes & W2A_FIX_ALERTS_2WKS) && env->tb.slot_hist2w >= W2A_ROW_FLOATS)
     return fail(W2A_ERR_SCHEMA, "w2a_set_semantics: slot_alerts_2wks out of range");
   env->tb.fixes = fixes;

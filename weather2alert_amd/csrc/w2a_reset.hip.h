@@ -54,8 +54,6 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     if (sm < 0 || sm >= a.tb.n_samples) { sm = 0; bad = 1; }
     ep.ep_row = (uint32_t)cw * (uint32_t)a.tb.Y + (uint32_t)yi;
     ep.ep_w = PACK_W(cc, sm);
-    // the logit-table path needs coefficient column == the weather county's own column
-    if (a.tb.weather_to_fips && a.tb.weather_to_fips[cw] != cc) bad |= 2;
     int32_t nd = a.tb.n_days[ep.ep_row];
     if (nd <= 0) { nd = 1; bad |= 1; }
     ep.ndays = (uint32_t)nd;
@@ -81,11 +79,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   if (valid && sel && l == 0) {
     if (a.from_tuples != 2) {
       store_episode(a.st, e, make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1),
-                    make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget),
-                    a.tb.Wendo, a.tb.n_samples);
+                    make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
     }
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
-    if (bad & 2) atomicOr(a.status, (int)W2A_ST_TABLE_MISMATCH);
     if (bad & 4) atomicOr(a.status, (int)W2A_ST_STEP_AFTER_DONE);
   }
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel, a.obs_f16 != 0);
@@ -94,8 +90,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
 __global__ void k_init_state(StateArrays st, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n)  // sticky = -1, episode_no = -1 (first reset -> 0); finished, so a step before reset() is flagged
-    store_episode(st, (uint32_t)i, make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u),
-                  nullptr, 0);
+    store_episode(st, (uint32_t)i, make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), make_uint4(0u, pack_d1(0, 1, 1), 0u, 0u));
 }
 
 __global__ void k_get_state(StateArrays st, int64_t n, int32_t Y, int32_t n_samples, w2a_state_view v) {

@@ -4,14 +4,13 @@
 #define W2A_SORT_HIP_H
 
 // ----------------------------------------------------------------------------------------
-// episode_order="sorted": relabel envs so that neighbours share coefficient / logit rows
+// episode_order="sorted": relabel envs so that neighbours share coefficient rows
 // ----------------------------------------------------------------------------------------
-__global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, int64_t n, int by_weather_row) {
+__global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint4 c = cold[i];
-  // gather path: coefficient row (column, draw) major, weather row minor; table path: weather row, then draw
-  keys[i] = by_weather_row ? (((uint64_t)c.x << SAMPLE_BITS) | W_SAMPLE(c.y)) : (((uint64_t)c.y << 32) | c.x);
+  keys[i] = ((uint64_t)c.y << 32) | c.x;  // coefficient row (column, draw) major, weather row minor
   idx[i] = (uint32_t)i;
 }
 __global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArrays dst, int64_t n) {
@@ -21,10 +20,6 @@ __global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArray
   dst.cold[i] = src.cold[j];
   dst.hot3[i] = src.hot3[j];
   dst.stepc[i] = src.stepc[j];
-  if (src.rtw) {
-    dst.rtw[2 * i] = src.rtw[2 * (size_t)j];
-    dst.rtw[2 * i + 1] = src.rtw[2 * (size_t)j + 1];
-  }
 }
 
 #endif  // W2A_SORT_HIP_H

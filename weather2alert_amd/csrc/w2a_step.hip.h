@@ -40,7 +40,7 @@ __device__ __forceinline__ int32_t load_action(const StepArgs &a, uint32_t e) {
 
 // One tile = the 16 envs of a wave, one day: everything of env.py:238-262 after the per-env state and action
 // have been loaded (the callers differ in how they schedule those first-hop loads).
-template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
+template <bool AUTORESET, bool WRITE_OBS, bool FIXES>
 __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave, int64_t wave_env0, int lane, int l,
                                           int grp, bool valid, uint32_t e, const uint4 cold, const uint4 hot,
                                           int32_t act) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
 #pragma unroll
   for (int q = 0; q < QUADS; ++q) {
     x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (WRITE_OBS || !TABLE) x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
+    x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
     if (WRITE_OBS) so[q] = reinterpret_cast<const int4 *>(a.slot_obs)[l * QUADS + q];
   }
   // env.py:190-193 run-time fields (slots 24..27)
@@ -83,21 +83,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
   if ((fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && l == a.tb.slot_hist2w / (4 * QUADS))
     set_comp(x, a.tb.slot_hist2w % (4 * QUADS), f_a2w);
   double zb, ze;
-  if (TABLE) {
-    // exogenous part of both logits (incl. bias and the heat_qi gate) was precomputed by k_logit_table;
-    // add the four run-time terms. Every lane of the group computes the same value (broadcast loads).
-    const double2 lv = a.tb.L[(size_t)day_row * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y)];
-    const float4 qb = a.st.rtw[2 * e];      // the env's run-time-slot coefficients, copied from Wendo at reset
-    const float4 qe = a.st.rtw[2 * e + 1];
-    zb = fma((double)f_lag1, (double)qb.x, lv.x);
-    zb = fma((double)f_streak, (double)qb.y, zb);
-    zb = fma((double)f_rem, (double)qb.z, zb);
-    zb = fma((double)f_a2w, (double)qb.w, zb);
-    ze = fma((double)f_lag1, (double)qe.x, lv.y);
-    ze = fma((double)f_streak, (double)qe.y, ze);
-    ze = fma((double)f_rem, (double)qe.z, ze);
-    ze = fma((double)f_a2w, (double)qe.w, ze);
-  } else {
+  {
     const float4 *wp = a.tb.W + wrow * (2 * ROWF / 4) + l * QUADS;
     float4 wb[QUADS], we[QUADS];
     // The effectiveness logit only enters the reward through eff * actual (env.py:221): without an alert today
@@ -173,7 +159,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     }
   }
   if (valid && l == 0) {
-    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2, a.tb.Wendo, a.tb.n_samples);
+    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2);
     else store_hot(a.st, e, hot2);
     a.reward[e] = r;
     a.done[e] = done ? 1 : 0;
@@ -187,7 +173,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
   }
 }
 
-template <bool AUTORESET, bool WRITE_OBS, bool TABLE, bool FIXES>
+template <bool AUTORESET, bool WRITE_OBS, bool FIXES>
 __global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) void k_step(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float s_tile[BLOCK / 64][ENVS_PER_WAVE * ROWF];
   const int tid = threadIdx.x;
@@ -209,7 +195,7 @@ __global__ __launch_bounds__(BLOCK, (AUTORESET || FIXES) ? 1 : W2A_MIN_WAVES) vo
     cold.w = full.w;
   }
   const int32_t act = load_action(a, e);
-  step_tile<AUTORESET, WRITE_OBS, TABLE, FIXES>(a, s_tile[wave], wave_env0, lane, l, grp, valid, e, cold, hot, act);
+  step_tile<AUTORESET, WRITE_OBS, FIXES>(a, s_tile[wave], wave_env0, lane, l, grp, valid, e, cold, hot, act);
 }
 
 #endif  // W2A_STEP_HIP_H

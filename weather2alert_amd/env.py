@@ -48,15 +48,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
     autoreset            "same_step" (finished envs restart inside the same step() call and the
                          returned observation is the new episode's first one; the finished
                          episode's return is in info["final_return"]) or "disabled".
-    reward_path          "gather": each step gathers the env's two 128-B coefficient rows and sums the 28
-                         terms (works for every episode); "table": logits come from a table precomputed once
-                         by a grouped fp64-MFMA GEMM (DeviceTables.build_logit_table) -- less memory traffic
-                         per step, but only for episodes whose coefficients are the weather county's own,
-                         i.e. without similar_climate_counties; "auto": the faster of the two (currently always
-                         "gather").
+    reward_path          "gather" (or "auto"): each step gathers the env's coefficient rows and sums the 28 terms. The
+                         precomputed logit-table path of round 1 ("table") was removed: it was slower at every batch
+                         size (each 16-B logit pair dragged a cold 128-B line of a 2 GB table).
     episode_order        "iid" (default): env i keeps its own independent draws, like N reference envs;
                          "sorted": after every (lock-step) reset the envs are relabelled so that env indices
-                         follow the coefficient / logit-table row. The batch holds exactly the same multiset of
+                         follow the coefficient row. The batch holds exactly the same multiset of
                          episodes, only which index holds which episode changes (env identity is not preserved
                          across episodes); neighbouring envs then share table lines and the step kernel's
                          gathers become L2 hits. Needs seed_mode="device" and a uniform episode length.
@@ -143,39 +140,31 @@ class HeatAlertVecEnv(_VectorEnvBase):
         else:
             ct = tables if tables is not None else compile_from_files(data_dir, weights, split, years)
             self.dtables = DeviceTables(ct, self.device)
-        if reward_path not in ("gather", "table", "auto"):
+        if reward_path == "table":
+            raise ValueError("reward_path='table' (the precomputed logit table of round 1) was removed: it was slower "
+                             "than the row-gather kernels at every batch size; use 'gather'")
+        if reward_path not in ("gather", "auto"):
             raise ValueError(f"reward_path {reward_path!r}")
-        if reward_path == "auto":
-            # measured: since the effectiveness row is fetched only on alert days the row-gather
-            # kernel beats the logit-table kernel at every batch size, so "auto" is the gather path
-            reward_path = "gather"
-        if reward_path == "table" and self.similar_climate_counties:
-            raise ValueError("reward_path='table' cannot serve similar_climate_counties=True (Q8 pairs a county's "
-                             "weather with another county's coefficients); use 'gather'")
+        reward_path = "gather"
         allf = set(_ffi.FIX_BITS) | {"budget"}
         self.fixes = set(allf) if (not faithful and fixes is None) else set(fixes or ())
         if self.fixes - allf:
             raise ValueError(f"unknown fixes {sorted(self.fixes - allf)}; choose from {sorted(allf)}")
-        if "alert_2wks" in self.fixes and reward_path == "table":
-            raise ValueError("fixes={'alert_2wks'} moves a coefficient out of the logit table; use reward_path='gather'")
         self.reward_path = reward_path
         if step_kernel not in ("auto", "classic"):
             raise ValueError(f"step_kernel {step_kernel!r}")
         self.step_kernel = step_kernel
         if reward_mode not in ("sampled", "posterior_mean"):
             raise ValueError(f"reward_mode {reward_mode!r}")
-        if reward_mode == "posterior_mean" and (self.fixes or reward_path == "table" or step_kernel != "auto"
-                                                or obs_dtype != torch.float32):
-            raise ValueError("reward_mode='posterior_mean' needs faithful semantics, reward_path='gather', "
-                             "step_kernel='auto' and float32 observations")
+        if reward_mode == "posterior_mean" and (self.fixes or step_kernel != "auto" or obs_dtype != torch.float32):
+            raise ValueError("reward_mode='posterior_mean' needs faithful semantics, step_kernel='auto' and float32 "
+                             "observations")
         self.reward_mode = reward_mode
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
         if episode_order == "sorted" and seed_mode != "device":
             raise ValueError("episode_order='sorted' needs seed_mode='device'")
         self.episode_order = episode_order
-        if reward_path == "table":
-            self.dtables.build_logit_table()
         ct = self.ct = self.dtables.ct
         self.fips_list = ct.fips_list
         self.valid_years = ct.years
@@ -279,7 +268,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._pm = self.reward_mode == "posterior_mean"
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
                             (_ffi.STEP_REWARD_GIVEN if self._pm else 0) |
-                            (_ffi.STEP_TABLE if self.reward_path == "table" else 0) |
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
 
@@ -312,10 +300,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
                            "(reference: KeyError at env.py:127 / ValueError at env.py:121)")
         if bits & _ffi.ST_BAD_ACTION:
             raise ValueError("step: actions must be 0 or 1 (action_space = Discrete(2))")
-        if (bits & _ffi.ST_TABLE_MISMATCH) and self.reward_path == "table":
-            raise ValueError("reset: an injected episode uses another county's coefficients; "
-                             "reward_path='table' cannot serve it (use 'gather')")
-        return bits & ~_ffi.ST_TABLE_MISMATCH
+        return bits
 
     def state(self) -> dict[str, torch.Tensor]:
         """Decoded per-env integer state (device tensors)."""
@@ -462,8 +447,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
             else:
                 s = int(seed) + i
             aug = bool(self._per_env(aug_o, i))
-            if aug and self.reward_path == "table":
-                raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
             w, y_i, li, ci, b, self._info_location[i] = numpy_parity_episode(
                 ct, s, self._per_env(loc_o, i), aug, self._sticky[i], self._per_env(bud_o, i),
                 bool(self._per_env(sb_o, i)), self._per_env(sbt_o, i), "augment" in self.fixes)
@@ -482,8 +465,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
             if self.ct.fips_to_weather[loc_i] < 0:
                 raise KeyError(loc)
         aug = bool(self._opt(options, "similar_climate_counties", self.similar_climate_counties))
-        if aug and self.reward_path == "table":
-            raise ValueError("reward_path='table' cannot serve similar_climate_counties=True; use 'gather'")
         if aug and loc_i >= 0 and self.ct.sim_cnt[loc_i] <= 0:
             raise KeyError(loc)  # county absent from the confounders: confounders.loc[fips] (datautils.py:123)
         bk = self._ctor_budget if self._ctor_budget is not None else options.get("budget")
@@ -526,8 +507,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                                 mask_t.data_ptr(), None if srt else obs_ptr, st),
                        "w2a_reset_device_rng")
             if srt:
-                _ffi.check(lib.w2a_sort_episodes(self._h, int(self.reward_path == "table"), self._sort_ws.data_ptr(),
-                                                 self._sort_ws.numel(), st), "w2a_sort_episodes")
+                _ffi.check(lib.w2a_sort_episodes(self._h, self._sort_ws.data_ptr(), self._sort_ws.numel(), st),
+                           "w2a_sort_episodes")
                 if obs_ptr is not None:
                     _ffi.check(lib.w2a_observe(self._h, obs_ptr, st), "w2a_observe")
         self._steps_in_episode = 0

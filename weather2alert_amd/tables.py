@@ -375,51 +375,8 @@ class DeviceTables:
         for j in range(_ffi.ROW_FLOATS):
             s.obs_slot[j] = ct.obs_slot[j] if j < ct.n_obs else -1
         s.slot_heat_qi = ct.slot_of["heat_qi"]
-        w2f = np.full(ct.S_w, -1, np.int32)
-        for i, w in enumerate(ct.fips_to_weather):
-            if w >= 0:
-                w2f[w] = i
-        self.weather_to_fips = t(w2f)
-        s.weather_to_fips = self.weather_to_fips.data_ptr()
         self.sim_ptr = t(ct.sim_ptr.astype(np.int32))
         self.sim_idx = t(ct.sim_idx.astype(np.int32) if len(ct.sim_idx) else np.zeros(1, np.int32))
         s.sim_ptr, s.sim_idx = self.sim_ptr.data_ptr(), self.sim_idx.data_ptr()
         s.slot_alerts_2wks = ct.slot_of.get("alerts_2wks", -1)
-        s.L, s.Wendo = None, None
-        self.L = self.Wendo = None
         self.struct = s
-        self.logit_build_ms = None
-
-    def build_logit_table(self, timed: bool = False):
-        """Dense reward precompute (include/w2a.h: w2a_build_logit_table): one grouped fp64-MFMA GEMM per
-        county -> L f64 [T][S_w*Y][n_samples][2] plus the 32-B run-time-slot coefficient rows. Enables
-        reward_path='table' for envs that do not use similar_climate_counties."""
-        import ctypes as C
-
-        import torch
-
-        from . import _ffi
-
-        if self.L is not None:
-            return self
-        lib = _ffi.load()
-        with torch.cuda.device(self.device):
-            lb = lib.w2a_logit_table_bytes(C.byref(self.struct))
-            wb = lib.w2a_wendo_bytes(C.byref(self.struct))
-            L = torch.empty(lb // 8, dtype=torch.float64, device=self.device)
-            Wendo = torch.empty(wb // 4, dtype=torch.float32, device=self.device)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            _ffi.check(lib.w2a_build_logit_table(C.byref(self.struct), L.data_ptr(), lb, Wendo.data_ptr(), wb,
-                                                 stream), "w2a_build_logit_table")
-            if timed:
-                e1.record()
-                torch.cuda.synchronize(self.device)
-                self.logit_build_ms = e0.elapsed_time(e1)
-        ct = self.ct
-        self.L = L.view(ct.T, ct.S_w * ct.Y, ct.n_samples, 2)
-        self.Wendo = Wendo.view(ct.S * ct.n_samples, 2, 4)
-        self.struct.L, self.struct.Wendo = L.data_ptr(), Wendo.data_ptr()
-        return self
