@@ -177,13 +177,6 @@ size_t w2a_group_workspace_bytes(int64_t num_envs);
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream);
 
-/* Opt-in observation format (no reference counterpart). W2A_OBS_F32 (default): obs buffers are float32
- * [num_envs][n_obs], bit-exact copies of the table values. W2A_OBS_F16: the `obs` pointers of w2a_reset*,
- * w2a_step and w2a_observe are IEEE half [num_envs][n_obs] (round-to-nearest-even) -- half the bytes of the
- * largest stream of a step, for policies that normalise their inputs anyway. */
-enum { W2A_OBS_F32 = 0, W2A_OBS_F16 = 1 };
-int w2a_set_obs_format(w2a_env *env, int format);
-
 /* First observation (env.py:181) of every env from its packed state; valid right after a reset
  * (t == 0 for every env, else W2A_ST_STEP_AFTER_DONE is raised). Used after w2a_sort_episodes. */
 int w2a_observe(w2a_env *env, float *obs, void *stream);

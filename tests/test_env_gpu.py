@@ -823,29 +823,6 @@ def test_step_is_hipgraph_capturable(dev):
     cap.close()
 
 
-def test_half_precision_observations_opt_in(dev):
-    """obs_dtype=float16: same trajectories, observations are the float32 rows rounded to half (RNE), on the
-    fast tile path, the ragged tail and across an autoreset."""
-    from weather2alert_amd import HeatAlertVecEnv
-
-    sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=12)
-    ct = tables.compile_from_synth(sd)
-    n = 1000 + 7
-    a32 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, step_kernel="classic")
-    a16 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, obs_dtype=torch.float16)
-    o32, _ = a32.reset(seed=3)
-    o16, _ = a16.reset(seed=3)
-    assert o16.dtype == torch.float16 and torch.equal(o16, o32.half())
-    g = torch.Generator(device="cpu").manual_seed(1)
-    for t in range(160):
-        act = (torch.rand(n, generator=g) < 0.2).to(torch.int32).to(dev)
-        o32, r32, d32, _, _ = a32.step(act)
-        o16, r16, d16, _, _ = a16.step(act)
-        assert torch.equal(o16, o32.half()) and torch.equal(r16, r32) and torch.equal(d16, d32)
-    a32.close()
-    a16.close()
-
-
 def test_other_schema_parity(dev):
     """A schema with one exogenous feature fewer (n_obs = 28): kernels, observation order and rewards still
     match the oracle, which derives everything from the column / key names as well."""

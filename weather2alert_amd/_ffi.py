@@ -21,9 +21,8 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_set_semantics",
-    "w2a_set_obs_format", "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
+    "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
 ]
-OBS_F32, OBS_F16 = 0, 1
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
 
 
@@ -112,8 +111,6 @@ def load(build_if_missing: bool = True):
     lib.w2a_posterior_mean_reward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.w2a_observe.restype = C.c_int
     lib.w2a_observe.argtypes = [vp, vp, vp]
-    lib.w2a_set_obs_format.restype = C.c_int
-    lib.w2a_set_obs_format.argtypes = [vp, C.c_int]
     lib.w2a_set_semantics.restype = C.c_int
     lib.w2a_set_semantics.argtypes = [vp, C.c_uint32]
     lib.w2a_rollout.restype = C.c_int

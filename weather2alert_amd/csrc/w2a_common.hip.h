@@ -146,7 +146,6 @@ struct w2a_env {
   const int32_t *slot_obs;  // [32] slot -> obs column (-1 none), in the state header
   StateArrays st;
   int32_t *status;
-  int32_t obs_f16;
   ResetCfg autoreset;
   int has_autoreset;
   int32_t obs_slot_host[ROWF];
@@ -283,12 +282,9 @@ __device__ __forceinline__ Episode draw_episode(const DevTables &tb, const Reset
 // x        : this lane's QUADS float4 of the row (slots 4*(l*QUADS+q)..), run-time fields already patched
 // so       : obs column of each of those slots (-1 = not part of the observation)
 // write_me : this env's row must be written (false -> keep what is in memory)
-// obs_f16: the caller's buffer is _Float16 [N][n_obs] (opt-in, w2a_set_obs_format): rows are converted with
-// round-to-nearest-even on the way out, 8 values per 16-B store.
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void store_obs_tile(void *__restrict__ obs_any, float *tile, int64_t wave_env0, int64_t n,
                                                int n_obs, int lane, int grp, const float4 *x, const int4 *so,
-                                               bool write_me, bool obs_f16 = false) {
+                                               bool write_me) {
   float *obs = reinterpret_cast<float *>(obs_any);
   // branch-free scatter: slots that are not observation columns (bias, gate flag, pads; so < 0) go to a scratch
   // word behind the packed rows (the tile has ENVS_PER_WAVE*32 floats, the rows use ENVS_PER_WAVE*n_obs <= 30*16)
@@ -306,28 +302,6 @@ __device__ __forceinline__ void store_obs_tile(void *__restrict__ obs_any, float
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const bool full = (wave_env0 + ENVS_PER_WAVE <= n);
   const bool all_write = __all(write_me || (wave_env0 + grp >= n));
-  if (obs_f16) {  // wave-uniform
-    _Float16 *dh = reinterpret_cast<_Float16 *>(obs_any) + wave_env0 * n_obs;
-    if (full && all_write) {
-      const int chunks = (ENVS_PER_WAVE * n_obs) >> 3;  // 16*n_obs halves = 2*n_obs chunks of 8
-      if (lane < chunks) {
-        const v4f a0 = reinterpret_cast<const v4f *>(tile)[2 * lane], a1 = reinterpret_cast<const v4f *>(tile)[2 * lane + 1];
-        v8h h = {(_Float16)a0.x, (_Float16)a0.y, (_Float16)a0.z, (_Float16)a0.w,
-                 (_Float16)a1.x, (_Float16)a1.y, (_Float16)a1.z, (_Float16)a1.w};
-        __builtin_nontemporal_store(h, reinterpret_cast<v8h *>(dh) + lane);
-      }
-    } else {
-      const int total = ENVS_PER_WAVE * n_obs;
-      const unsigned long long wm = __ballot(write_me);
-      for (int i = lane; i < total; i += 64) {
-        int g = i / n_obs;
-        bool w = (wm >> (g * LANES)) & 1ull;
-        if (w && wave_env0 + g < n) dh[i] = (_Float16)tile[i];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return;
-  }
   float *dst = obs + wave_env0 * n_obs;
   if (full && all_write) {
     const int chunks = (ENVS_PER_WAVE * n_obs) >> 2;  // ENVS_PER_WAVE*n_obs floats is a multiple of 4

@@ -111,7 +111,6 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.stepc = h->st.hot3 + num_envs;
   h->status = status;
   h->has_autoreset = 0;
-  h->obs_f16 = 0;
   h->perm = nullptr;
   h->perm_valid = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
@@ -137,7 +136,7 @@ static unsigned grid_for(int64_t n) {
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   if (a.from_tuples != 2) env->perm_valid = 0;  // new episode tuples: the column grouping is stale
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
-  a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.obs_f16 = env->obs_f16;
+  a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
   hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
@@ -191,9 +190,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
   const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
   const bool given = (flags & W2A_STEP_REWARD_GIVEN) != 0;
-  if (given && (autoreset || env->tb.fixes || env->obs_f16 || (flags & W2A_STEP_CLASSIC)))
+  if (given && (autoreset || env->tb.fixes || (flags & W2A_STEP_CLASSIC)))
     return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is served by the 64-envs-per-wave kernel only (no in-kernel "
-                             "autoreset, no corrected-semantics flags, f32 observations)");
+                             "autoreset, no corrected-semantics flags)");
   if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
   if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
@@ -202,13 +201,12 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
-  a.obs_f16 = env->obs_f16;
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
 #if W2A_F64_SIGMOID
   if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
 #else
-  if (!autoreset && !env->tb.fixes && !env->obs_f16 && !(flags & W2A_STEP_CLASSIC)) {
+  if (!autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
     const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
@@ -326,13 +324,6 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
   hipLaunchKernelGGL(k_posterior_mean, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
-  return W2A_OK;
-}
-
-int w2a_set_obs_format(w2a_env *env, int format) {
-  if (!env) return fail(W2A_ERR_ARG, "w2a_set_obs_format: NULL handle");
-  if (format != W2A_OBS_F32 && format != W2A_OBS_F16) return fail(W2A_ERR_ARG, "w2a_set_obs_format: unknown format");
-  env->obs_f16 = (format == W2A_OBS_F16) ? 1 : 0;
   return W2A_OK;
 }
 

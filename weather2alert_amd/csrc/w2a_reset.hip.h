@@ -13,7 +13,6 @@ struct ResetArgs {
   const int32_t *county_w, *year_i, *coef_col, *sample, *budget;  // host-tuple mode
   const uint8_t *mask;
   void *obs;
-  int32_t obs_f16;
   int32_t *status;
   int64_t n;
   int64_t gid0;
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 4) atomicOr(a.status, (int)W2A_ST_STEP_AFTER_DONE);
   }
-  if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel, a.obs_f16 != 0);
+  if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }
 
 __global__ void k_init_state(StateArrays st, int64_t n) {

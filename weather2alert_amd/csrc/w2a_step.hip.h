@@ -11,7 +11,7 @@ struct StepArgs {
   const int32_t *slot_obs;
   StateArrays st;
   const void *actions;
-  void *obs;  // f32 [n][n_obs], or _Float16 [n][n_obs] when obs_f16
+  void *obs;  // f32 [n][n_obs]
   float *reward;
   uint8_t *done;
   float *last_return;
@@ -20,7 +20,6 @@ struct StepArgs {
   int64_t gid0;
   ResetCfg rc;
   int32_t act_dtype;
-  int32_t obs_f16;
 };
 
 #ifndef W2A_MIN_WAVES
@@ -169,7 +168,7 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     if (st_bits) atomicOr(a.status, (int)st_bits);
   }
   if (WRITE_OBS) {
-    store_obs_tile(a.obs, s_tile_wave, wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, write_row, a.obs_f16 != 0);
+    store_obs_tile(a.obs, s_tile_wave, wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, write_row);
   }
 }
 

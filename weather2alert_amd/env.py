@@ -69,13 +69,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          alert_lag1 is yesterday's action), "penalty" (Q5: -1 for an alert attempted at budget),
                          "obs" (Q6: step() returns the next day's row), "augment" (Q8: the drawn similar county
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
-    obs_dtype            torch.float32 (default, bit-exact table values) or torch.float16 (opt-in: observations are
-                         rounded to half on the way out -- half the bytes of the largest stream of a step).
     reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
                          "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
                          reward form -- computed by a grouped fp64-MFMA GEMM per step (csrc/w2a_posterior.hip.h).
-                         Needs lock-step / disabled autoreset, faithful semantics, float32 observations.
+                         Needs lock-step / disabled autoreset and faithful semantics.
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches on the row-gather path run
                          the 64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env
                          kernel; "classic" forces the latter (same results up to the order of the fp64 additions;
@@ -110,7 +108,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
         lockstep: bool | None = None,
         faithful: bool = True,
         fixes: set | list | None = None,
-        obs_dtype: torch.dtype = torch.float32,
         step_kernel: Literal["auto", "classic"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
     ):
@@ -156,9 +153,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self.step_kernel = step_kernel
         if reward_mode not in ("sampled", "posterior_mean"):
             raise ValueError(f"reward_mode {reward_mode!r}")
-        if reward_mode == "posterior_mean" and (self.fixes or step_kernel != "auto" or obs_dtype != torch.float32):
-            raise ValueError("reward_mode='posterior_mean' needs faithful semantics, step_kernel='auto' and float32 "
-                             "observations")
+        if reward_mode == "posterior_mean" and (self.fixes or step_kernel != "auto"):
+            raise ValueError("reward_mode='posterior_mean' needs faithful semantics and step_kernel='auto'")
         self.reward_mode = reward_mode
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
@@ -182,9 +178,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
             nbytes = self._lib.w2a_state_bytes(n)
             self._state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
-            if obs_dtype not in (torch.float32, torch.float16):
-                raise ValueError("obs_dtype must be torch.float32 or torch.float16")
-            self._obs = torch.zeros((n, ct.n_obs), dtype=obs_dtype, device=dev)
+            self._obs = torch.zeros((n, ct.n_obs), dtype=torch.float32, device=dev)
             self._reward = torch.zeros(n, dtype=torch.float32, device=dev)
             self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
             self._final_return = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -193,8 +187,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
             _ffi.check(self._lib.w2a_create(C.byref(self.dtables.struct), n, self.env_gid0, self._state.data_ptr(),
                                             nbytes, self._status.data_ptr(), C.byref(h)), "w2a_create")
         self._h = h
-        if obs_dtype == torch.float16:
-            _ffi.check(self._lib.w2a_set_obs_format(h, _ffi.OBS_F16), "w2a_set_obs_format")
         bits = sum(_ffi.FIX_BITS[k] for k in self.fixes if k in _ffi.FIX_BITS)
         if bits:
             _ffi.check(self._lib.w2a_set_semantics(h, bits), "w2a_set_semantics")
