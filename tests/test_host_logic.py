@@ -82,3 +82,37 @@ def test_corrected_augmentation_uses_the_drawn_county(gold):
     w1, _, li1, _, _, info1 = rng.numpy_parity_episode(ct, 21, loc, True, None, None, False, "less_than", True)
     assert info0 == info1 and ct.fips_weather[w0] == loc  # faithful: weather of the requested county (Q8)
     assert ct.fips_list[li1] == info1 and ct.fips_weather[w1] == info1 and li0 < ct.sim_cnt[ct.fips_list.index(loc)]
+
+
+def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monkeypatch):
+    """HeatAlertVecEnv subclasses gymnasium.vector.VectorEnv when the package can be imported (it is absent from
+    the build image, so a stand-in module is injected) and carries the VectorEnv attributes either way."""
+    import importlib
+    import sys
+    import types
+
+    class FakeVectorEnv:
+        metadata: dict = {}
+
+    gym = types.ModuleType("gymnasium")
+    vec = types.ModuleType("gymnasium.vector")
+    vec.VectorEnv = FakeVectorEnv
+    gym.vector = vec
+    monkeypatch.setitem(sys.modules, "gymnasium", gym)
+    monkeypatch.setitem(sys.modules, "gymnasium.vector", vec)
+    import weather2alert_amd.env as envmod
+
+    try:
+        m = importlib.reload(envmod)
+        assert issubclass(m.HeatAlertVecEnv, FakeVectorEnv)
+        cls = m.HeatAlertVecEnv
+        assert cls.metadata["autoreset_mode"] == "same_step" and cls.spec is None and cls.render_mode is None
+        for attr in ("np_random", "np_random_seed", "unwrapped"):
+            assert isinstance(getattr(cls, attr), property)
+        for meth in ("reset", "step", "close"):
+            assert callable(getattr(cls, meth))
+    finally:
+        monkeypatch.delitem(sys.modules, "gymnasium")
+        monkeypatch.delitem(sys.modules, "gymnasium.vector")
+        importlib.reload(envmod)
+    assert envmod.HeatAlertVecEnv.__mro__[1] is object
