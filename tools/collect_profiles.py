@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the judged rocprof evidence from gpurun_out/ (scratch) into profiles/<tag>/ (tracked):
-trimmed kernel-stats CSV, per-kernel PMC means, the calibration of FETCH_SIZE/WRITE_SIZE on
-kernels of known byte counts, and profiles/traffic_latest.json that bench.py reports as
-roofline.traffic.
+"""Copy the judged rocprof evidence from gpurun_out/ (scratch) into profiles/<round>/ (tracked):
+trimmed kernel-stats CSV of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`, per-kernel PMC means of the
+tools/pmc_probe.py passes, the in-process calibration of FETCH_SIZE / WRITE_SIZE on kernels of known byte counts, and
+profiles/traffic_latest.json, which bench.py reports as roofline.traffic when the kernel sources still hash to the
+`src_sha` recorded here.
 
-    python tools/collect_profiles.py r01 [--workload configs2]
+    python tools/collect_profiles.py r02 configs2 configs2_sorted configs3_pm
 """
 import argparse
 import csv
@@ -12,81 +13,100 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO = os.path.join(ROOT, "gpurun_out")
 GIB = float(1 << 30)
+KEEP = ("k_step", "k_reset", "k_posterior", "k_rollout", "k_group", "copyBuffer", "FillFunctor")
 
 
-def main():
-    p = argparse.ArgumentParser()
-    p.add_argument("tag")
-    p.add_argument("--workload", default="configs2")
-    p.add_argument("--kernel", default="k_step<true, true>")
-    a = p.parse_args()
-    out = os.path.join(ROOT, "profiles", a.tag)
-    os.makedirs(out, exist_ok=True)
-    # 1. rocprofv3 --kernel-trace --stats summary of `python3 bench.py` (names trimmed)
-    ks = glob.glob(os.path.join(GO, f"prof_kt_{a.workload}", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    f = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+def collect(tag, out, rnd):
+    # 1. rocprofv3 --kernel-trace --stats summary of bench.py (names trimmed)
+    ks = newest(os.path.join(GO, f"prof_kt_{tag}", "**", "*kernel_stats.csv"))
     if ks:
-        ks.sort(key=os.path.getmtime)  # gpurun merges every session's files into gpurun_out/: take the newest
-        rows = list(csv.reader(open(ks[-1])))
-        with open(os.path.join(out, f"kernel_stats_{a.workload}.csv"), "w", newline="") as f:
+        rows = list(csv.reader(open(ks)))
+        with open(os.path.join(out, f"kernel_stats_{tag}.csv"), "w", newline="") as f:
             w = csv.writer(f)
             for r in rows:
                 r[0] = r[0][:100]
                 w.writerow(r)
+    log = os.path.join(GO, f"prof_kt_{tag}.log")
+    if os.path.exists(log):
+        line = [ln for ln in open(log).read().splitlines() if ln.startswith('{"metric"')]
+        if line:
+            open(os.path.join(out, f"bench_under_rocprof_{tag}.json"), "w").write(line[-1] + "\n")
     # 2. PMC passes (tools/pmc_probe.py): per-kernel means
     pmc = {}
-    for name in ("prof_fetch", "prof_write", "prof_tcc", "prof_sq", "prof_mfma"):
-        fp = os.path.join(GO, f"{name}_{a.workload}.summary.json")
+    for name in ("prof_fetch", "prof_write", "prof_tcc", "prof_sq", "prof_sq2", "prof_mfma"):
+        fp = os.path.join(GO, f"{name}_{tag}.summary.json")
         if os.path.exists(fp):
             for k, v in json.load(open(fp)).items():
-                if "k_step" in k or "k_reset" in k or "k_logit" in k or "copyBuffer" in k or "FillFunctor" in k:
+                if any(x in k for x in KEEP):
                     pmc.setdefault(k, {}).update({kk: vv for kk, vv in v.items() if not kk.endswith("_n")})
-    # calibration from the raw CSVs: the 1 GiB copy / fill launches are the big ones
+    # calibration from the raw CSVs: the 1 GiB copy launches of the probe
     calib = {}
     for name, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
-        cc = sorted(glob.glob(os.path.join(GO, f"{name}_{a.workload}", "**", "*counter_collection.csv"),
-                              recursive=True), key=os.path.getmtime)
-        for f in cc[-1:]:
+        f = newest(os.path.join(GO, f"{name}_{tag}", "**", "*counter_collection.csv"))
+        if f:
             per = {}
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == ctr:
                     key = (r["Dispatch_Id"], r["Kernel_Name"][:60])
                     per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
-            for (d, k), v in per.items():
-                if "copyBuffer" in k and v > 1e5:
-                    calib.setdefault(f"copy_1GiB_{ctr}_KB", []).append(v)
-                if "FillFunctor" in k and ctr == "WRITE_SIZE" and 1.0e6 < v < 1.1e6:
-                    calib.setdefault("fill_1GiB_WRITE_SIZE_KB", []).append(v)
-    calib = {k: sum(v) / len(v) for k, v in calib.items()}
-    kk = [k for k in pmc if a.kernel in k]
-    res = {"workload": a.workload, "pmc": pmc, "calibration": calib}
-    if kk and "FETCH_SIZE" in pmc[kk[0]] and "WRITE_SIZE" in pmc[kk[0]]:
+            vals = [v for (d, k), v in per.items() if "copyBuffer" in k and v > 1e5]
+            if vals:
+                calib[f"copy_1GiB_{ctr}_KB"] = sum(vals) / len(vals)
+    probe = {}
+    pj = os.path.join(GO, f"pmc_probe_{tag}.json")
+    if os.path.exists(pj):
+        probe = json.load(open(pj))
+    res = {"tag": tag, "probe": probe, "pmc": pmc, "calibration": calib}
+    main = "k_posterior_mean" if tag.endswith("_pm") else probe.get("step_kernel", "k_step64")
+    kk = [k for k in pmc if main in k and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
+    if kk:
         e = pmc[kk[0]]
-        # MI355X_MICROARCH.md §HBM: counters are in KB (x1024); on gfx950 FETCH_SIZE reports 1/2 of the bytes of
-        # 16-B-per-lane reads (confirmed here: a 1 GiB copy reads FETCH_SIZE = 524288 KB), WRITE_SIZE is exact
+        # MI355X_MICROARCH.md §HBM: counters are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane
+        # reads (confirmed in-process: a 1 GiB copy reads FETCH_SIZE = 524288 KB), WRITE_SIZE is exact
         rd_corr = GIB / (calib["copy_1GiB_FETCH_SIZE_KB"] * 1024) if "copy_1GiB_FETCH_SIZE_KB" in calib else 2.0
         wr_corr = GIB / (calib["copy_1GiB_WRITE_SIZE_KB"] * 1024) if "copy_1GiB_WRITE_SIZE_KB" in calib else 1.0
-        rd = e["FETCH_SIZE"] * 1024 * rd_corr
-        wr = e["WRITE_SIZE"] * 1024 * wr_corr
-        res["traffic"] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
-                          "read_correction": rd_corr, "write_correction": wr_corr,
-                          "avg_us": e.get("avg_us")}
-        tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        cur = json.load(open(tl)) if os.path.exists(tl) else {}
-        cur[a.workload] = rd + wr
-        json.dump(cur, open(tl, "w"), indent=1)
-    json.dump(res, open(os.path.join(out, f"pmc_{a.workload}.json"), "w"), indent=1)
-    logs = ["bench.log", "pytest_gpu.log", "smoke.log"] + [os.path.basename(x) for x in
-                                                           glob.glob(os.path.join(GO, "bench_*.log"))]
+        rd, wr = e["FETCH_SIZE"] * 1024 * rd_corr, e["WRITE_SIZE"] * 1024 * wr_corr
+        res["traffic"] = {"kernel": kk[0], "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                          "bytes_per_launch": rd + wr, "read_correction": rd_corr, "write_correction": wr_corr,
+                          "kernel_avg_us": e.get("avg_us")}
+        if not tag.endswith("_pm") and probe.get("src_sha"):
+            tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            cur = json.load(open(tl)) if os.path.exists(tl) else {}
+            cur = {k: v for k, v in cur.items() if isinstance(v, dict)}
+            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                    text=True).stdout.strip()
+            cur[tag] = dict(res["traffic"], src_sha=probe["src_sha"], step_kernel=probe.get("step_kernel"),
+                            commit=commit, profile=f"profiles/{rnd}/pmc_{tag}.json")
+            json.dump(cur, open(tl, "w"), indent=1)
+    json.dump(res, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=1)
+    print(tag, json.dumps(res.get("traffic"), indent=1))
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("round")
+    p.add_argument("tags", nargs="*", default=["configs2"])
+    a = p.parse_args()
+    out = os.path.join(ROOT, "profiles", a.round)
+    os.makedirs(out, exist_ok=True)
+    for tag in a.tags:
+        collect(tag, out, a.round)
+    logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log"]
+    logs += [os.path.basename(x) for x in glob.glob(os.path.join(GO, "bench_*.log"))]
     for f in logs:
         src = os.path.join(GO, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(out, f))
-    print(json.dumps(res.get("traffic"), indent=1))
-    print(json.dumps(calib, indent=1))
 
 
 if __name__ == "__main__":

@@ -150,6 +150,7 @@ struct w2a_env {
   int has_autoreset;
   int32_t obs_slot_host[ROWF];
   const uint32_t *perm;  // env ids sorted by coefficient column (w2a_group_by_column), valid until the next reset
+  uint4 *prep;           // per-step scratch of the posterior-mean path, inside the same workspace
   int perm_valid;
 };
 

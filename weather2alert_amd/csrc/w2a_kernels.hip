@@ -112,6 +112,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
+  h->prep = nullptr;
   h->perm_valid = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
@@ -285,7 +286,7 @@ static size_t cub_group_bytes(int64_t n) {
 
 size_t w2a_group_workspace_bytes(int64_t num_envs) {
   if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
-  return align256(4 * (size_t)num_envs) * 4 + align256(cub_group_bytes(num_envs));
+  return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + align256(cub_group_bytes(num_envs));
 }
 
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
@@ -294,7 +295,8 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace must be 256-B aligned");
   const size_t n = (size_t)env->n;
   char *p = (char *)workspace;
-  uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first: stays valid after the call
+  uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first two: stay in use after the call
+  env->prep = (uint4 *)p;          p += align256(16 * n);
   uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
   uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
@@ -319,8 +321,10 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: not available with corrected-semantics flags");
   PosteriorArgs a;
   memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.st = env->st; a.perm = env->perm; a.actions = actions; a.act_dtype = action_dtype;
+  a.tb = env->tb; a.st = env->st; a.perm = env->perm; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
   a.reward = reward; a.status = env->status; a.n = env->n;
+  hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
   hipLaunchKernelGGL(k_posterior_mean, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());

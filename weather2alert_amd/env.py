@@ -509,6 +509,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
     def _regroup(self):
         """posterior_mean: env ids sorted by coefficient column for the grouped GEMM; after EVERY reset."""
         if self._group_ws is not None:
+            if max(int(self.ct.B0.max()), int(self._ctor_budget or 0), int(self._last_opts.get("budget") or 0)) > 65535:
+                raise ValueError("reward_mode='posterior_mean' packs remaining_budget into 16 bits: budgets <= 65535")
             with torch.cuda.device(self.device):
                 _ffi.check(self._lib.w2a_group_by_column(self._h, self._group_ws.data_ptr(), self._group_ws.numel(),
                                                          self._stream()), "w2a_group_by_column")
