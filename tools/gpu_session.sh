@@ -29,6 +29,13 @@ for step in "$@"; do
         timeout -k 10 300 python bench.py --no-cpu-baseline --steps 612 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iid %.2f us  always-alert %.2f us  sorted %.2f us  e2e %.2f G/s' % (d['roofline']['avg_launch_us'], d['always_alert_policy']['kernel_us'], d['sorted_episode_order']['kernel_us'], d['value']/1e9))" | tee -a gpurun_out/ab2.log
       done
       python -c "from weather2alert_amd import build; build.build_lib(force=True)" ;;
+    benchall)
+      for w in configs1 configs3; do
+        timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/bench_$w.log 2>&1; echo "bench $w exit $?"; tail -1 gpurun_out/bench_$w.log | cut -c1-300
+      done ;;
+    gloo2)
+      # two ranks sharing the one GPU over gloo: the whole multi-rank path of bench.py except RCCL itself
+      timeout -k 10 300 python bench.py --gpus 2 --backend gloo --num-envs 262144 --steps 306 --no-cpu-baseline > gpurun_out/bench_gloo2.log 2>&1; echo "gloo2 exit $?"; tail -1 gpurun_out/bench_gloo2.log | cut -c1-400 ;;
     bench)
       timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-3000 ;;
     benchab)
@@ -56,7 +63,7 @@ for step in "$@"; do
       fi
       R=$PWD
       rm -rf gpurun_out/prof_*_$tag
-      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt_$tag -- python3 bench.py --workload $w $bextra --no-cpu-baseline > gpurun_out/prof_kt_$tag.log 2>&1; echo "prof_kt $tag exit $?"
+      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt_$tag -- python3 bench.py --workload $w $bextra --no-cpu-baseline --no-extras > gpurun_out/prof_kt_$tag.log 2>&1; echo "prof_kt $tag exit $?"
       for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "sq2:SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
         name=${grp%%:*}; ctrs=${grp#*:}
         timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w $extra > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
