@@ -34,7 +34,7 @@ for q in (0.7, 0.8, 0.9, 0.95):
                        alert_mask=True)
     s = HeatAlertVecEnv.episode_stats(out)
     print(f"threshold {q}: mean return {s['mean_return']:.2f}, alerts/episode {s['mean_alerts']:.2f}, "
-          f"80% of alerts issued by day {s['day_80pct_alerts']:.0f}")
+          f"80% of alerts issued by day {s['alert_t_80%']:.0f}, over-budget frequency {s['over_budget_freq']:.4f}")
 envs.close()
 
 # 3. the drop-in for weather2alert.env.HeatAlertEnv (same reset/step signatures, NumPy-seed parity)

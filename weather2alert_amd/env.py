@@ -624,33 +624,19 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 self._launch_device_reset(None, self._obs_ptr)
         return out
 
-    @staticmethod
-    def episode_stats(out: dict) -> dict:
-        """Batch statistics of finished rollouts -- what the reference's SB3 callbacks try to log
-        (callbacks.py:18-87): mean return, alerts per episode, how often alerts were attempted over budget,
-        the histogram of alert days, alert-streak mean/std, and the day by which 50/80/100 % of an episode's
-        alerts were issued. Needs rollout(..., alert_mask=True) for the day-resolved entries."""
+    @classmethod
+    def episode_stats(cls, out: dict) -> dict:
+        """Batch summary of finished rollouts: mean return, alerts per episode, alerts attempted over budget per
+        episode, the histogram of alert days (needs rollout(..., alert_mask=True)) and, for whole-episode rollouts
+        with alert_mask=True, everything the reference's logging callback reports (callback_stats: same keys and
+        definitions as callbacks.py:61-77)."""
         s = {"mean_return": float(out["return"].double().mean()),
              "mean_alerts": float(out["alerts"].double().mean()),
-             "over_budget_freq": float((out["attempts_over_budget"] > 0).double().mean()),
              "mean_attempts_over_budget": float(out["attempts_over_budget"].double().mean())}
         if "alert_days" in out:
-            a = out["alert_days"]
-            s["alert_day_hist"] = a.sum(0).cpu()
-            af = a.to(torch.int32)
-            starts = af[:, :1].clone()
-            starts = torch.cat([starts, (af[:, 1:] == 1) & (af[:, :-1] == 0)], 1).to(torch.int32)
-            n_streaks = starts.sum(1)
-            has = n_streaks > 0
-            mean_len = af.sum(1)[has].double() / n_streaks[has].double()
-            s["streak_mean"] = float(mean_len.mean()) if has.any() else 0.0
-            s["streak_std"] = float(mean_len.std()) if has.sum() > 1 else 0.0
-            cum = af.cumsum(1)
-            tot = cum[:, -1:]
-            for q in (50, 80, 100):
-                need = torch.ceil(tot.double() * q / 100.0)
-                day = ((cum.double() >= need) & (tot > 0)).to(torch.int32).argmax(1)
-                s[f"day_{q}pct_alerts"] = float(day[has].double().mean()) if has.any() else float("nan")
+            s["alert_day_hist"] = out["alert_days"].sum(0).cpu()
+            if bool(out["done"].all()) and bool((out["first_day"] == 0).all()):
+                s.update(cls.callback_stats(out))
         return s
 
     @staticmethod
