@@ -82,7 +82,7 @@ def parse(argv=None):
                         "small batches); the timed region still runs exactly --steps steps")
     p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
                    help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
-    p.add_argument("--step-kernel", default="auto", choices=["auto", "classic"])
+    p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the multi-rank path (ranks share the GPUs there are; with the "
                         "launcher_stub workload it needs no GPU at all)")
@@ -413,7 +413,7 @@ def main():
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
         cb = compulsory_bytes(ct.n_obs, not args.no_obs)
         achieved = cb["total"] * n / per_launch_s / 1e9
-        variant = "k_step64" if (env.step_kernel == "auto" and not env._dev_auto and not env.fixes) else "k_step"
+        variant = env.step_kernel_name
         kname = f"{variant}<obs={not args.no_obs}>" + (" (in-kernel autoreset)" if env._dev_auto else
                                                          " + k_reset once per episode")
         # fabric traffic from the PMC passes, only if collected on these very kernel sources

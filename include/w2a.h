@@ -54,6 +54,8 @@ enum {
   W2A_STEP_NO_OBS = 2,    /* reward-only: skip the observation write */
   W2A_STEP_CLASSIC = 8,   /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
+  W2A_STEP_WIDE = 32,     /* force the 64-envs-per-wave kernel for small batches too (by default it serves batches of
+                             >= 131 072 envs, the 4-lanes-per-env kernel smaller ones: the faster one on MI355X) */
   W2A_STEP_REWARD_GIVEN = 16 /* `reward` is an INPUT: it already holds today's reward of every env
                              (w2a_posterior_mean_reward on the same state and actions); the step does everything
                              else of env.py:238-262 and accumulates that reward into the episode return */

@@ -119,7 +119,7 @@ def _random_tuples(ct, n, rng, augment):
 
 
 @pytest.mark.parametrize("n,augment,adversarial,kernel", [
-    (4099, False, False, "auto"), (65536, True, False, "auto"), (8192, False, True, "auto"),
+    (4099, False, False, "wide"), (65536, True, False, "wide"), (8192, False, True, "wide"),
     (4099, False, False, "classic"), (8192, False, True, "classic")])
 def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, kernel):
     """HIP path vs the float64 vector oracle over a full 153-step episode on a synthetic data set
@@ -173,7 +173,8 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     ct = tables.compile_from_synth(sd)
     ep = _random_tuples(ct, n, rng, True)
     kw = dict(tables=ct, device=dev, autoreset="disabled", write_obs=write_obs)
-    new, old = HeatAlertVecEnv(n, **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
+    new, old = HeatAlertVecEnv(n, step_kernel="wide", **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
+    assert new.step_kernel_name == "k_step64" and old.step_kernel_name == "k_step"
     o1, _ = new.reset(options={"episodes": ep})
     o2, _ = old.reset(options={"episodes": ep})
     assert torch.equal(o1, o2)
@@ -840,7 +841,7 @@ def test_other_schema_parity(dev):
     county = rng.integers(0, ct.S, n)
     ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
               sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 9, n))
-    for kernel in ("auto", "classic"):
+    for kernel in ("wide", "classic"):
         env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel=kernel)
         obs, _ = env.reset(options={"episodes": ep})
         assert obs.shape == (n, 28)

@@ -91,7 +91,7 @@ def test_reference_full_size_anchor_episodes(golden_dir, dev):
             assert env.alert_streak == d["streak_after"][i, t] and env.t == d["t_after"][i, t]
         env.close()
     # (2) the same six episodes as one batch of injected tuples, on both step kernels
-    for kernel in ("auto", "classic"):
+    for kernel in ("wide", "classic"):
         v = HeatAlertVecEnv(E, tables=dt, device=dev, autoreset="disabled", step_kernel=kernel)
         obs, _ = v.reset(options={"episodes": dict(county_w=cw, year_i=yi, coef_col=d["location_index"],
                                                    sample=d["coef_index"], budget=d["budget"])})
@@ -112,6 +112,7 @@ def test_reference_full_size_anchor_episodes(golden_dir, dev):
 
 @pytest.mark.parametrize("config,weights,n,augment,kernel", [
     ("configs[1]", "linear", 65536, False, "auto"),
+    ("configs[1]", "linear", 65536, False, "wide"),
     ("configs[2]", "linear", 1 << 20, True, "auto"),
     ("configs[3]", "nn_full_medicare_all", 1 << 20, False, "classic"),
     ("configs[3]", "nn_full_medicare_all", 1 << 20, False, "auto"),
@@ -126,6 +127,7 @@ def test_baseline_shapes_vs_oracle(dev, config, weights, n, augment, kernel):
     assert ct.S == (746 if weights == "linear" else 720) and ct.Y == 11 and ct.n_samples == 100 and ct.T == 153
     env = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=augment, autoreset="disabled",
                           step_kernel=kernel)
+    assert env.step_kernel_name == ("k_step" if kernel == "classic" or (kernel == "auto" and n < 131072) else "k_step64")
     obs, _ = env.reset(seed=20 + n % 7)
     idx = np.unique(np.concatenate([np.arange(0, n, max(n // 65536, 1)), [n - 1]]))
     it = torch.as_tensor(idx, device=dev)

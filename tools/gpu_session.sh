@@ -36,6 +36,10 @@ for step in "$@"; do
     gloo2)
       # two ranks sharing the one GPU over gloo: the whole multi-rank path of bench.py except RCCL itself
       timeout -k 10 300 python bench.py --gpus 2 --backend gloo --num-envs 262144 --steps 306 --no-cpu-baseline > gpurun_out/bench_gloo2.log 2>&1; echo "gloo2 exit $?"; tail -1 gpurun_out/bench_gloo2.log | cut -c1-400 ;;
+    nsweep)
+      for n in 16384 65536 131072 262144 524288; do
+        timeout -k 10 300 python tools/exp_step_kernels.py --quick --num-envs $n --tag "n=$n " 2>&1 | grep -v amdgpu.ids | grep "random" | tee -a gpurun_out/nsweep.log
+      done ;;
     bench)
       timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-3000 ;;
     benchab)

@@ -22,7 +22,7 @@ p.add_argument("--workload", default="configs2")
 p.add_argument("--steps", type=int, default=24)
 p.add_argument("--num-envs", type=int, default=None)
 p.add_argument("--no-obs", action="store_true")
-p.add_argument("--step-kernel", default="auto", choices=["auto", "classic"])
+p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
 p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"])
 p.add_argument("--reward-mode", default="sampled", choices=["sampled", "posterior_mean"])
 a = p.parse_args()
@@ -36,6 +36,7 @@ env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment
 g = torch.Generator(device=dev).manual_seed(1234)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
 env.reset(seed=0)
+env_kernel = env.step_kernel_name
 # calibration: 1 GiB copy (reads 1 GiB, writes 1 GiB) and 1 GiB fill, float32
 src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 dst = torch.empty_like(src)
@@ -55,7 +56,7 @@ os.makedirs("gpurun_out", exist_ok=True)
 tag = (a.workload + ("_noobs" if a.no_obs else "") + ("_sorted" if a.episode_order == "sorted" else "")
        + ("_pm" if a.reward_mode == "posterior_mean" else ""))
 json.dump({"workload": tag, "src_sha": wbuild.source_sha(), "num_envs": n, "steps": a.steps,
-           "step_kernel": "k_step64" if a.step_kernel == "auto" else "k_step"},
+           "step_kernel": env_kernel},
           open(f"gpurun_out/pmc_probe_{tag}.json", "w"))
 print("probe done", desc, "steps", a.steps)
 env.close()

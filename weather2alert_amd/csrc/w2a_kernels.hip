@@ -207,7 +207,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
 #if W2A_F64_SIGMOID
   if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
 #else
-  if (!autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
+  // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
+  // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
+  const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
+  if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
     const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));

@@ -18,6 +18,9 @@
 //   C  lane = env          sigmoid, reward, return accumulator; reward / done / state written as whole lines
 // What is computed is identical to k_step<false, WRITE_OBS, false, false> up to the order of the fp64 additions
 // (4-term chains + 8-lane tree instead of 8-term chains + 4-lane tree: ~1e-16 relative on the logits).
+#ifndef W2A_S64_MIN_ENVS
+#define W2A_S64_MIN_ENVS 131072     // batch size from which w2a_step picks this kernel by itself
+#endif
 #define S64_ENVS 64                 // envs per wave
 #define S64_WAVES (BLOCK / 64)
 #define S64_PASS_ENVS 32            // envs per observation flush (4 rounds of 8)

@@ -74,10 +74,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
                          reward form -- computed by a grouped fp64-MFMA GEMM per step (csrc/w2a_posterior.hip.h).
                          Needs lock-step / disabled autoreset and faithful semantics.
-    step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches on the row-gather path run
-                         the 64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env
-                         kernel; "classic" forces the latter (same results up to the order of the fp64 additions;
-                         for A/B measurements).
+    step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
+                         64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
+                         (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
+                         results up to the order of the fp64 additions; for A/B measurements and tests).
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -108,7 +108,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         lockstep: bool | None = None,
         faithful: bool = True,
         fixes: set | list | None = None,
-        step_kernel: Literal["auto", "classic"] = "auto",
+        step_kernel: Literal["auto", "classic", "wide"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
     ):
         self._lib = _ffi.load()
@@ -148,13 +148,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if self.fixes - allf:
             raise ValueError(f"unknown fixes {sorted(self.fixes - allf)}; choose from {sorted(allf)}")
         self.reward_path = reward_path
-        if step_kernel not in ("auto", "classic"):
+        if step_kernel not in ("auto", "classic", "wide"):
             raise ValueError(f"step_kernel {step_kernel!r}")
         self.step_kernel = step_kernel
         if reward_mode not in ("sampled", "posterior_mean"):
             raise ValueError(f"reward_mode {reward_mode!r}")
-        if reward_mode == "posterior_mean" and (self.fixes or step_kernel != "auto"):
-            raise ValueError("reward_mode='posterior_mean' needs faithful semantics and step_kernel='auto'")
+        if reward_mode == "posterior_mean" and (self.fixes or step_kernel == "classic"):
+            raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
@@ -261,7 +261,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
                             (_ffi.STEP_REWARD_GIVEN if self._pm else 0) |
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
+                            (_ffi.STEP_WIDE if self.step_kernel == "wide" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
+
+    @property
+    def step_kernel_name(self) -> str:
+        """The step kernel w2a_step launches for this env right now (mirrors the dispatch in csrc/w2a_kernels.hip)."""
+        wide = self._pm or self.step_kernel == "wide" or (self.step_kernel == "auto" and
+                                                          self.num_envs >= _ffi.S64_MIN_ENVS)
+        return "k_step64" if (wide and not self._dev_auto and not (self.fixes - {"budget"})
+                              and self.step_kernel != "classic") else "k_step"
 
     def _stream(self):
         if self._raw_stream is not None:
