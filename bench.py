@@ -439,7 +439,12 @@ def main():
                        "policy": "Bernoulli(0.1) actions from a device RNG, table budgets",
                        "seed_mode": "device", "autoreset": "same_step", "reward_path": "gather",
                        "step_kernel": variant, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
-                       "collective": "all_gather_into_tensor(f32[num_envs_per_gpu]) per episode" if world > 1 else "none"},
+                       "collective": "all_gather_into_tensor(f32[num_envs_per_gpu]) per episode" if world > 1 else "none",
+                       "single_gpu_reference": f"python bench.py --gpus 1 --workload {args.workload}"
+                                               + (f" --num-envs {n}" if args.num_envs else "") +
+                                               " (the N = 1 default is configs2, a different table shape: compare "
+                                               "multi-GPU values with THIS workload on one GPU)" if world > 1 else None},
+            "per_gpu_value": total_env_steps / wall / world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["bytes_per_launch"],

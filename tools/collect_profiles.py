@@ -101,8 +101,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     for tag in a.tags:
         collect(tag, out, a.round)
-    logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log"]
-    logs += [os.path.basename(x) for x in glob.glob(os.path.join(GO, "bench_*.log"))]
+    logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
+            "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log"]
     for f in logs:
         src = os.path.join(GO, f)
         if os.path.exists(src):

@@ -40,6 +40,8 @@ for step in "$@"; do
       for n in 16384 65536 131072 262144 524288; do
         timeout -k 10 300 python tools/exp_step_kernels.py --quick --num-envs $n --tag "n=$n " 2>&1 | grep -v amdgpu.ids | grep "random" | tee -a gpurun_out/nsweep.log
       done ;;
+    rollout)
+      timeout -k 10 300 python tools/bench_rollout.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_rollout.log ;;
     bench)
       timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench.log | cut -c1-3000 ;;
     benchab)
