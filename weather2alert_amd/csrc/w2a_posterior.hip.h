@@ -19,8 +19,12 @@
 //     kernels, closed gate = -inf logit, per-row sums over draws in fp64, 16-lane DPP all-reduce, one f32 per env.
 // The step kernel then runs with W2A_STEP_REWARD_GIVEN and does everything else of env.py:238-262.
 #define PM_ROWS 256                // sorted positions per workgroup: 16 row tiles of 16, 4 per wave
+static_assert(PM_ROWS == BLOCK, "one thread per row in the set-up phase");
 #define PM_TILES_PER_WAVE (PM_ROWS / 16 / (BLOCK / 64))
 #define PM_NPAD 112                // draws per staging pass (7 MFMA column tiles)
+#ifndef W2A_PM_EXPERIMENT
+#define W2A_PM_EXPERIMENT 0
+#endif
 typedef double pm_double4 __attribute__((ext_vector_type(4)));
 
 struct PosteriorArgs {
@@ -162,33 +166,53 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
         // effectiveness enters only through eff * gate * actual: when no row of this tile has an open gate AND an
         // alert today (most tiles: alerts are budget-limited), its half of the GEMM and its sigmoids are skipped
         const bool any_eff = __any(ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f || ga[3] != 0.0f);
-        // software pipeline: the next B fragment is read from LDS before the current MFMAs are issued
-        PmB nxt = pm_load_b(sB[0], q, lane & 15);
-        for (int nt = 0; nt < tiles; ++nt) {
+        // one 16-draw tile: 8 (+ 8) MFMAs and the epilogue. The effectiveness fragment is read from LDS before the
+        // baseline MFMAs are issued, the NEXT tile's baseline fragment (into `nb`) before the effectiveness ones:
+        // LDS latency sits under 512 cycles of MFMA. Two named buffers alternate (the loop is unrolled by two), so
+        // no fragment is ever copied between registers.
+        auto do_tile = [&](int nt, const PmB &cb, PmB &nb) {
           const int nn = nt * 16 + (lane & 15);
-          const PmB cb = nxt;
-          if (any_eff) nxt = pm_load_b(sB[1], q, nn);
-          else if (nt + 1 < tiles) nxt = pm_load_b(sB[0], q, nn + 16);
+          PmB ce;
+          if (any_eff) ce = pm_load_b(sB[1], q, nn);
+          else if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
           pm_double4 accb = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
+#if W2A_PM_EXPERIMENT == 2  // timing experiment: VALU FMA instead of MFMA (results wrong)
+#pragma unroll
+          for (int ks = 0; ks < ROWF / 4; ++ks) accb[ks & 3] = fma(ad[ks], (double)cb.v[ks], accb[ks & 3]);
+#else
 #pragma unroll
           for (int ks = 0; ks < ROWF / 4; ++ks)
             accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
+#endif
           if (any_eff) {  // wave-uniform
-            const PmB ce = nxt;
-            if (nt + 1 < tiles) nxt = pm_load_b(sB[0], q, nn + 16);
+            if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
+#if W2A_PM_EXPERIMENT == 2
+#pragma unroll
+            for (int ks = 0; ks < ROWF / 4; ++ks) acce[ks & 3] = fma(ad[ks], (double)ce.v[ks], acce[ks & 3]);
+#else
 #pragma unroll
             for (int ks = 0; ks < ROWF / 4; ++ks)
               acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)ce.v[ks], acce, 0, 0, 0);
+#endif
           }
           if (n0 + nn < n_samples) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // D[row = q + 4 j][col = lane & 15]
+#if W2A_PM_EXPERIMENT == 1  // timing experiment: no sigmoid epilogue (results wrong)
+              rs[j] += (float)accb[j] + (float)acce[j];
+#else
               const float base = sigmoid_f32((float)accb[j]);
               float keep = 1.0f;
               if (any_eff) keep = 1.0f - sigmoid_f32((float)acce[j]) * ga[j];
               rs[j] += base * keep;
+#endif
             }
           }
+        };
+        PmB b0 = pm_load_b(sB[0], q, lane & 15), b1;
+        for (int nt = 0; nt < tiles; nt += 2) {
+          do_tile(nt, b0, b1);
+          if (nt + 1 < tiles) do_tile(nt + 1, b1, b0);
         }
         // sum over the 16 lanes that share q (one DPP row): xor 1, xor 2, half mirror, mirror
 #pragma unroll
