@@ -1008,3 +1008,50 @@ def test_callback_statistics_and_episode_csv(dev, kind, tmp_path):
     assert rd[0] == list(O.CSV_FIELDS) and len(rd) == n + 1
     assert rd[1][0] == str(rows_o[0]["year"]) and rd[1][-1] == str(rows_o[0]["alerts"])
     env.close()
+
+
+@pytest.mark.timeout(180)
+def test_rccl_single_rank_return_gather(dev):
+    """The collective path of dist.ReturnGatherer on the real backend: backend "nccl" (= RCCL on ROCm) with a
+    one-rank group on this GPU -- process-group creation with device_id, all_gather_into_tensor of the episodic
+    returns and the scalar all_reduce run through RCCL itself (multi-rank runs need more than one GPU; the
+    world-size-2 logic is covered on gloo in tests/test_dist_cpu.py)."""
+    import socket
+
+    import torch.distributed as dist
+
+    from weather2alert_amd import HeatAlertVecEnv
+    from weather2alert_amd import dist as wdist
+
+    if not dist.is_nccl_available():
+        pytest.skip("no RCCL in this torch build")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=4)
+        ct = tables.compile_from_synth(sd)
+        n = 4096
+        env = HeatAlertVecEnv(n, tables=ct, device=dev)
+        env.reset(seed=1)
+        a = torch.zeros(n, dtype=torch.int32, device=dev)
+        for _ in range(153):
+            _, _, done, _, info = env.step(a)
+        assert done.all()
+        g = wdist.ReturnGatherer(n, dev)
+        assert g.world == 1
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, info["final_return"].contiguous())  # the call gather() makes for world > 1
+        torch.cuda.synchronize()
+        assert torch.equal(out, info["final_return"])
+        m = info["final_return"].double().sum().reshape(1)
+        dist.all_reduce(m)
+        assert abs(float(m) / n - float(g.mean(info["final_return"]))) < 1e-9
+        assert wdist.max_over_ranks(1.5, dev) == 1.5
+        wdist.barrier()
+        env.close()
+    finally:
+        dist.destroy_process_group()

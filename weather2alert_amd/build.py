@@ -34,18 +34,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > m for d in deps)
 
 
-def source_sha() -> str:
-    """sha256 over the kernel sources and the ABI header (file names + contents): identifies the build that a
-    profile was collected on, independently of commits that do not touch the kernels."""
+STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_kernels.hip")
+
+
+def source_sha(files: tuple = STEP_SOURCES) -> str:
+    """sha256 over the sources the step kernels are built from and the ABI header (file names + contents):
+    identifies the build a step-kernel profile was collected on, independently of commits that do not touch them."""
     import hashlib
 
     h = hashlib.sha256()
     csrc = os.path.dirname(SRC)
-    for f in sorted(os.listdir(csrc)) + [os.path.join(INC, "w2a.h")]:
-        path = f if os.path.isabs(f) else os.path.join(csrc, f)
-        if path.endswith((".hip", ".hip.h", ".h")):
-            h.update(os.path.basename(path).encode())
-            h.update(open(path, "rb").read())
+    for path in [os.path.join(csrc, f) for f in sorted(files)] + [os.path.join(INC, "w2a.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 
