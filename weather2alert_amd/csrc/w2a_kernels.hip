@@ -56,10 +56,14 @@ extern "C" {
 int w2a_abi_version(void) { return W2A_ABI_VERSION; }
 const char *w2a_last_error(void) { return g_err; }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// header (slot map) + cold 16 B + hot3 12 B + stepc 12 B per env, every array on its own 256-B boundary (for odd
+// env counts the 12-B arrays would otherwise start at a 4-B boundary and their 12-B loads straddle lines)
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
-  size_t b = HDR_BYTES + (size_t)num_envs * 40 + 16;  // cold 16 + hot3 12 + stepc 12
-  return (b + 255) & ~(size_t)255;
+  const size_t n = (size_t)num_envs;
+  return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n);
 }
 
 int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *state, size_t state_bytes,
@@ -107,8 +111,8 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->gid0 = env_gid0;
   h->slot_obs = reinterpret_cast<const int32_t *>(state);
   h->st.cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
-  h->st.hot3 = reinterpret_cast<u3 *>(h->st.cold + num_envs);
-  h->st.stepc = h->st.hot3 + num_envs;
+  h->st.hot3 = reinterpret_cast<u3 *>((char *)h->st.cold + align256(16 * (size_t)num_envs));
+  h->st.stepc = reinterpret_cast<u3 *>((char *)h->st.hot3 + align256(12 * (size_t)num_envs));
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
@@ -236,7 +240,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
 }
 
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t cub_sort_bytes(int64_t n) {
   size_t b = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr,
