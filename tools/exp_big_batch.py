@@ -5,7 +5,7 @@ from weather2alert_amd import HeatAlertVecEnv, synth, tables
 sd = synth.make_synth("nn_full_medicare_all", years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
 dev = torch.device("cuda:0")
-for n in (8388608, 8388608 + 13):
+for n in [int(x) for x in sys.argv[1:]] or (8388608, 8388608 + 13):
     env = HeatAlertVecEnv(n, tables=ct, device=dev)
     obs, _ = env.reset(seed=1)
     a = (torch.rand(n, device=dev) < 0.1).to(torch.uint8)
