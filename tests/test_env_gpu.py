@@ -727,13 +727,14 @@ def test_budget_invariants_at_scale(dev):
     env.close()
 
 
-def test_checkpoint_resume_is_bit_exact(dev):
+@pytest.mark.parametrize("mode", ["sampled", "posterior_mean"])
+def test_checkpoint_resume_is_bit_exact(dev, mode):
     from weather2alert_amd import HeatAlertVecEnv
 
     sd = synth.make_synth("linear", n_fips=16, years=[2006, 2007], n_samples=4, seed=8)
     ct = tables.compile_from_synth(sd)
     n = 1500
-    env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, reward_mode=mode)
     env.reset(seed=2)
     g = torch.Generator(device="cpu").manual_seed(3)
     acts = [(torch.rand(n, generator=g) < 0.2).to(torch.int32).to(dev) for _ in range(260)]
@@ -741,7 +742,8 @@ def test_checkpoint_resume_is_bit_exact(dev):
         env.step(a)
     ck = env.state_dict()
     ref = [tuple(x.clone() for x in env.step(a)[:3]) for a in acts[120:]]  # crosses an episode boundary (autoreset)
-    other = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+    other = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, reward_mode=mode)
+    other.reset(seed=99)  # a different batch first: the restore must also rebuild the posterior-mean column grouping
     other.load_state_dict(ck)
     for a, (o, r, d) in zip(acts[120:], ref):
         o2, r2, d2, _, _ = other.step(a)

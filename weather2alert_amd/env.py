@@ -353,6 +353,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if self._reset_cfg is not None:
             with torch.cuda.device(self.device):
                 _ffi.check(self._lib.w2a_set_autoreset(self._h, *self._reset_cfg), "w2a_set_autoreset")
+        self._regroup()  # posterior_mean: the restored episode tuples need their own column grouping
 
     # ------------------------------------------------------------------ reset
     def _opt(self, options, key, default):
