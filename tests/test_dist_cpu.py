@@ -44,6 +44,13 @@ def _worker(rank, world, port, n_local, q):
     allr = g.gather(local)
     expect = -100.0 - torch.arange(n_local * world, dtype=torch.float32)
     ok = torch.equal(allr, expect)
+    # overlapped form: the returns are snapshotted, so the env may overwrite its buffer while the collective runs
+    mine = local.clone()
+    out = g.gather(mine, async_op=True)
+    mine.fill_(123.0)
+    ok = ok and torch.equal(g.wait(), expect) and out is g.out and g._work is None
+    g.gather(local, async_op=True)
+    ok = ok and torch.equal(g.gather(local * 2), expect * 2)  # a new gather first completes the pending one
     m = float(g.mean(local))
     mx = wdist.max_over_ranks(float(rank + 1), dev)
     wdist.barrier()

@@ -1043,12 +1043,14 @@ def test_rccl_single_rank_return_gather(dev):
         for _ in range(153):
             _, _, done, _, info = env.step(a)
         assert done.all()
-        g = wdist.ReturnGatherer(n, dev)
-        assert g.world == 1
-        out = torch.empty(n, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(out, info["final_return"].contiguous())  # the call gather() makes for world > 1
+        g = wdist.ReturnGatherer(n, dev, force_collective=True)  # the path gather() takes for world > 1
+        assert g.world == 1 and g._collective
+        want = info["final_return"].clone()
+        out = g.gather(info["final_return"], async_op=True)  # enqueued on RCCL's stream, launch stream not blocked
+        env.step(a)  # the next episode's work overlaps the collective
         torch.cuda.synchronize()
-        assert torch.equal(out, info["final_return"])
+        assert torch.equal(g.wait(), want) and out is g.out
+        assert torch.equal(g.gather(want), want)  # blocking form
         m = info["final_return"].double().sum().reshape(1)
         dist.all_reduce(m)
         assert abs(float(m) / n - float(g.mean(info["final_return"]))) < 1e-9

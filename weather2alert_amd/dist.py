@@ -39,23 +39,49 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
 
 class ReturnGatherer:
     """All-gather of the per-env episodic returns f32[n_local] -> f32[world * n_local]
-    (equal shard sizes) with one ``all_gather_into_tensor``; on one rank it is a no-op view."""
+    (equal shard sizes) with one ``all_gather_into_tensor``; on one rank it is a no-op view.
 
-    def __init__(self, n_local: int, device, world: int | None = None):
+    ``gather(x, async_op=True)`` overlaps the collective with the next episode's steps: the returns are
+    snapshotted into a private buffer (the env overwrites its own on the next terminal step), the collective is
+    enqueued without blocking the launch stream (RCCL runs it on the process group's own stream), and ``wait()``
+    makes the current stream wait for it before ``out`` is consumed. One collective may be in flight; starting
+    another waits for the previous one first."""
+
+    def __init__(self, n_local: int, device, world: int | None = None, force_collective: bool = False):
         self.world = (dist.get_world_size() if dist.is_initialized() else 1) if world is None else world
         self.n_local = int(n_local)
         self.out = torch.empty(self.world * self.n_local, dtype=torch.float32, device=device)
+        # force_collective: run the collective even in a one-rank group (exercises RCCL on a single GPU)
+        self._collective = self.world > 1 or (force_collective and dist.is_initialized())
+        self._src = torch.empty(self.n_local, dtype=torch.float32, device=device) if self._collective else None
+        self._work = None
+        self._staged = None
 
-    def gather(self, local_returns: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+    def gather(self, local_returns: torch.Tensor, async_op: bool = False) -> torch.Tensor:
+        self.wait()
+        if not self._collective:
             self.out.copy_(local_returns)
-        elif dist.get_backend() == "gloo" and local_returns.is_cuda:
+            return self.out
+        if dist.get_backend() == "gloo" and local_returns.is_cuda:
             # rehearsal path (several ranks on one GPU / no RCCL): gloo has no CUDA all-gather, stage on the host
             tmp = torch.empty(self.out.shape, dtype=self.out.dtype)
-            dist.all_gather_into_tensor(tmp, local_returns.cpu().contiguous())
-            self.out.copy_(tmp)
+            self._work = dist.all_gather_into_tensor(tmp, local_returns.cpu().contiguous(), async_op=True)
+            self._staged = tmp
         else:
-            dist.all_gather_into_tensor(self.out, local_returns.contiguous())
+            self._src.copy_(local_returns)
+            self._work = dist.all_gather_into_tensor(self.out, self._src, async_op=True)
+        if not async_op:
+            self.wait()
+        return self.out
+
+    def wait(self) -> torch.Tensor:
+        """Order the pending collective (if any) before whatever the current stream does next with ``out``."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if self._staged is not None:
+                self.out.copy_(self._staged)
+                self._staged = None
         return self.out
 
     def mean(self, local_returns: torch.Tensor) -> torch.Tensor:
