@@ -179,22 +179,25 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
 #if W2A_PM_EXPERIMENT == 2  // timing experiment: VALU FMA instead of MFMA (results wrong)
 #pragma unroll
           for (int ks = 0; ks < ROWF / 4; ++ks) accb[ks & 3] = fma(ad[ks], (double)cb.v[ks], accb[ks & 3]);
-#else
-#pragma unroll
-          for (int ks = 0; ks < ROWF / 4; ++ks)
-            accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
-#endif
-          if (any_eff) {  // wave-uniform
+          if (any_eff) {
             if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
-#if W2A_PM_EXPERIMENT == 2
 #pragma unroll
             for (int ks = 0; ks < ROWF / 4; ++ks) acce[ks & 3] = fma(ad[ks], (double)ce.v[ks], acce[ks & 3]);
+          }
 #else
+          if (any_eff) {  // wave-uniform: two independent accumulation chains, interleaved
+            if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
+#pragma unroll
+            for (int ks = 0; ks < ROWF / 4; ++ks) {
+              accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
+              acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)ce.v[ks], acce, 0, 0, 0);
+            }
+          } else {
 #pragma unroll
             for (int ks = 0; ks < ROWF / 4; ++ks)
-              acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)ce.v[ks], acce, 0, 0, 0);
-#endif
+              accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
           }
+#endif
           if (n0 + nn < n_samples) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // D[row = q + 4 j][col = lane & 15]

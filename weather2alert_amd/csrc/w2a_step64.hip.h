@@ -68,6 +68,9 @@ struct S64Wave {
 #ifndef W2A_S64_SC1
 #define W2A_S64_SC1 0
 #endif
+#ifndef W2A_S64_SKIP_EFF
+#define W2A_S64_SKIP_EFF 1  // skip the effectiveness dot product in rounds where no env alerts today (A/B)
+#endif
 #ifndef W2A_S64_NT_STATE
 #define W2A_S64_NT_STATE 0  // A/B: bit 0 = hot3, bit 1 = stepc loaded non-temporally
 #endif
@@ -170,19 +173,25 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       zb = fma(x1, (double)wb[r].y, zb);
       zb = fma(x2, (double)wb[r].z, zb);
       zb = fma(x3, (double)wb[r].w, zb);
-      double ze = x0 * (double)we[r].x;
-      ze = fma(x1, (double)we[r].y, ze);
-      ze = fma(x2, (double)we[r].z, ze);
-      ze = fma(x3, (double)we[r].w, ze);
-      // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds the 0/1 flag with a zero coefficient; a
-      // closed gate drives the logit to -inf so that the sigmoid is exactly 0
-      if (p == GATE_QUAD && !(x[r].z > 0.5f)) ze = -__builtin_inf();
       zb += dpp_f64<0xB1>(zb);   // lane ^ 1
-      ze += dpp_f64<0xB1>(ze);
       zb += dpp_f64<0x4E>(zb);   // lane ^ 2
-      ze += dpp_f64<0x4E>(ze);
       zb += dpp_f64<0x141>(zb);  // row_half_mirror: the other quad of the 8-lane group
-      ze += dpp_f64<0x141>(ze);
+      double ze = 0.0;
+#if W2A_S64_SKIP_EFF
+      if (__any(need[r]))  // wave-uniform: most rounds have no alert today (eff * actual = 0 whatever eff is)
+#endif
+      {
+        ze = x0 * (double)we[r].x;
+        ze = fma(x1, (double)we[r].y, ze);
+        ze = fma(x2, (double)we[r].z, ze);
+        ze = fma(x3, (double)we[r].w, ze);
+        // effectiveness gate heat_qi > 0.5 (env.py:218): slot 30 holds the 0/1 flag with a zero coefficient; a
+        // closed gate drives the logit to -inf so that the sigmoid is exactly 0
+        if (p == GATE_QUAD && !(x[r].z > 0.5f)) ze = -__builtin_inf();
+        ze += dpp_f64<0xB1>(ze);
+        ze += dpp_f64<0x4E>(ze);
+        ze += dpp_f64<0x141>(ze);
+      }
       if (p == 0) sw.z[j] = make_float2((float)zb, (float)ze);
       }
       if (WRITE_OBS) {
