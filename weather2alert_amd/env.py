@@ -875,16 +875,31 @@ class HeatAlertEnv:
         self.observation_space = self._v.single_observation_space
         self.action_space = self._v.single_action_space
         self.feat_names = ct.feature_names
+        self._act = torch.zeros(1, dtype=torch.int32, device=self._v.device)
 
     @property
     def budget(self):
         return self._v._sticky[0]
 
     def _sync_state(self):
-        buf, _ = self._v._state_packed()
-        host = buf.cpu().numpy()[:, 0]  # one device-to-host copy for all fields
-        st = {k: host[i] for i, k in enumerate(_ffi.STATE_FIELDS)}
-        ct = self._v.ct
+        """One device-to-host copy per call: observation, reward, done, the status word and every decoded state
+        field are concatenated on the device (the reference's API returns Python scalars, so each call must
+        synchronise once -- but only once)."""
+        v = self._v
+        buf, _ = v._state_packed()
+        pack = torch.cat([v._obs.view(torch.int32).reshape(-1), v._reward.view(torch.int32),
+                          v._done.to(torch.int32), v._status, buf.reshape(-1)])
+        host = pack.cpu().numpy()
+        n_obs = v.ct.n_obs
+        self._h_obs = host[:n_obs].view(np.float32).copy()
+        self._h_reward = float(host[n_obs: n_obs + 1].view(np.float32)[0])
+        self._h_done = bool(host[n_obs + 1])
+        bits = int(host[n_obs + 2])
+        if bits:  # rare: let check_status() read-and-clear the word and raise what the reference raises
+            v.check_status()
+        fields = host[n_obs + 3:]
+        st = {k: fields[i] for i, k in enumerate(_ffi.STATE_FIELDS)}
+        ct = v.ct
         self.t = int(st["t"])
         self.alert_streak = int(st["streak"])
         self.coef_index = int(st["sample"])
@@ -892,7 +907,7 @@ class HeatAlertEnv:
         self.remaining_budget = int(st["budget"] - st["used"])
         self.at_budget = bool(st["at_budget"])
         self.n_days = int(st["n_days"])
-        self.location = self._v._info_location[0]
+        self.location = v._info_location[0]
         self.ep_index = ct.fips_weather[int(st["county_w"])] + "_" + str(ct.years[int(st["year_i"])])
         return st
 
@@ -909,17 +924,16 @@ class HeatAlertEnv:
         obs, _ = self._v.reset(seed=[seed], options=dict(
             location=location, similar_climate_counties=similar_climate_counties, budget=budget,
             sample_budget=sample_budget, sample_budget_type=sample_budget_type))
-        self._v.check_status()
         self._sync_state()
-        self.observation = obs[0].cpu().numpy().copy()
+        self.observation = self._h_obs
         return self.observation, self._get_info()
 
     def step(self, action: int):
-        obs, r, done, _, _ = self._v.step(torch.tensor([int(action)], dtype=torch.int32, device=self._v.device))
-        self._v.check_status()
+        self._act.fill_(int(action))
+        self._v.step(self._act)
         self._sync_state()
-        self.observation = obs[0].cpu().numpy().copy()
-        return self.observation, float(r[0].item()), bool(done[0].item()), False, self._get_info()
+        self.observation = self._h_obs
+        return self.observation, self._h_reward, self._h_done, False, self._get_info()
 
     def close(self):
         self._v.close()
