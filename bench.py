@@ -310,6 +310,9 @@ def main():
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if args.backend == 'gloo' else local}")
     torch.cuda.set_device(device)
     wdist.init_from_env(args.backend, device)
+    if local == 0:  # one rank per node (re)builds libw2a.so if its sources are newer; the others wait and load it
+        wbuild.build_lib()
+    wdist.barrier()
 
     wname, n_default, augment, desc = WORKLOADS[args.workload]
     n = args.num_envs or n_default
