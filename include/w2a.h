@@ -96,6 +96,11 @@ typedef struct w2a_tables {
   const int32_t *sim_ptr;         /* [S+1] CSR of similar(county) ∩ fips_list, confounders order (W2A_FIX_AUGMENT)     */
   const int32_t *sim_idx;         /* weight-column index of each similar county                                       */
   int32_t slot_alerts_2wks;       /* slot of the historical 'alerts_2wks' column, -1 = absent (W2A_FIX_ALERTS_2WKS)    */
+  /* optional (NULL = off): the gate flags of slot 30 as a bitmap, [T][gate_words] uint32, bit (row & 31) of word
+   * row >> 5 for row = county_w * Y + year_i. Lets the 64-envs-per-wave step kernel know in its first phase whether
+   * the effectiveness row is needed at all (alert today AND heat_qi > 0.5, env.py:218-221) before any row is gathered */
+  const uint32_t *gate_bits;
+  int32_t gate_words;             /* words per day = ceil(S_w * Y / 32)                                               */
 } w2a_tables;
 
 typedef struct w2a_env w2a_env; /* opaque handle: pointers + dims only */

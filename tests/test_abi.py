@@ -49,8 +49,8 @@ def test_host_only_entry_points(lib):
 
 
 def test_ffi_struct_layout_matches_header():
-    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 2 pointers + 1 int32 (+4 pad), naturally aligned
-    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 2 * 8 + 8
+    # 6 pointers + 6 int32 + 32 int32 + 1 int32 (+4 pad) + 2 pointers + 1 int32 (+4 pad) + 1 pointer + 1 int32 (+4 pad)
+    assert C.sizeof(_ffi.Tables) == 6 * 8 + (6 + 32 + 1) * 4 + 4 + 2 * 8 + 8 + 8 + 8
     assert C.sizeof(_ffi.StateView) == 16 * 8
 
 

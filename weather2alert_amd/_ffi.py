@@ -40,6 +40,7 @@ class Tables(C.Structure):
         ("T", C.c_int32), ("S_w", C.c_int32), ("Y", C.c_int32), ("S", C.c_int32), ("n_samples", C.c_int32),
         ("n_obs", C.c_int32), ("obs_slot", C.c_int32 * ROW_FLOATS), ("slot_heat_qi", C.c_int32),
         ("sim_ptr", C.c_void_p), ("sim_idx", C.c_void_p), ("slot_alerts_2wks", C.c_int32),
+        ("gate_bits", C.c_void_p), ("gate_words", C.c_int32),
     ]
 
 

@@ -109,6 +109,8 @@ struct DevTables {
   const float4 *W;
   const int32_t *fips_to_weather;
   const int32_t *sim_cnt;
+  const uint32_t *gate_bits;       // [T][gate_words] bitmap of the slot-30 gate flags; nullable
+  int32_t gate_words;
   const int32_t *sim_ptr;          // [S+1] CSR of similar(county) ∩ fips_list (only for W2A_FIX_AUGMENT); nullable
   const int32_t *sim_idx;
   int32_t T, S_w, Y, S, n_samples, n_obs;

@@ -104,6 +104,12 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->tb.sim_ptr = t->sim_ptr;
   h->tb.sim_idx = t->sim_idx;
   h->tb.slot_hist2w = t->slot_alerts_2wks;
+  h->tb.gate_bits = t->gate_bits;
+  h->tb.gate_words = t->gate_words;
+  if (t->gate_bits && (int64_t)t->gate_words * 32 < (int64_t)t->S_w * t->Y) {
+    delete h;
+    return fail(W2A_ERR_SCHEMA, "w2a_create: gate_words * 32 must cover S_w * Y rows");
+  }
   h->tb.fixes = 0;
   h->tb.T = t->T; h->tb.S_w = t->S_w; h->tb.Y = t->Y; h->tb.S = t->S; h->tb.n_samples = t->n_samples;
   h->tb.n_obs = t->n_obs;

@@ -125,12 +125,19 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   const uint32_t actual = d.actual, atb = d.atb, st_bits = d.st_bits;
   const int32_t budget = d.budget;
   const bool done = d.done;
+  // The effectiveness logit enters the reward through eff * gate * actual (env.py:218-221): its coefficient row is
+  // fetched only for envs that alert today AND whose gate is open. The gate flag of (day, row) comes from a 1 KB
+  // per-day bitmap (L2-resident) when the tables carry one; without it every alerting env fetches the row and the
+  // closed gate acts through the -inf logit.
+  uint32_t need_eff = actual;
+  if (a.tb.gate_bits && actual)
+    need_eff = (a.tb.gate_bits[t * (uint32_t)a.tb.gate_words + (c.b >> 5)] >> (c.b & 31u)) & 1u;
   {
     // feature row of day t (pre-increment, Q6) and the env's coefficient rows, as float4 indices (32-bit: table
     // sizes are validated in w2a_create). The effectiveness row is fetched only on alert days (k_step).
     const uint32_t day_row = t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b;
     const uint32_t wrow = W_COL(c.c) * (uint32_t)a.tb.n_samples + W_SAMPLE(c.c);
-    sw.desc[lane] = make_uint2(day_row * (ROWF / 4), (wrow * (2 * ROWF / 4)) | (actual << 31));
+    sw.desc[lane] = make_uint2(day_row * (ROWF / 4), (wrow * (2 * ROWF / 4)) | (need_eff << 31));
     sw.rt[lane] = runtime_fields(d);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -257,8 +264,8 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   } else {
     const float2 z = sw.z[lane];
     const float base = sigmoid_f32(z.x);  // env.py:211-221
-    const float eff = sigmoid_f32(z.y);
-    r = -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
+    const float eff = need_eff ? sigmoid_f32(z.y) : 0.0f;  // not needed = no alert or closed gate: eff * actual = 0
+    r = -(1000.0f / 152.0f) * base * (1.0f - eff);
   }
   const uint32_t t2 = done ? t : t + 1;
   const uint32_t streak2 = done ? streak : (actual ? streak + 1 : 0);  // env.py:260

@@ -379,4 +379,12 @@ class DeviceTables:
         self.sim_idx = t(ct.sim_idx.astype(np.int32) if len(ct.sim_idx) else np.zeros(1, np.int32))
         s.sim_ptr, s.sim_idx = self.sim_ptr.data_ptr(), self.sim_idx.data_ptr()
         s.slot_alerts_2wks = ct.slot_of.get("alerts_2wks", -1)
+        # gate bitmap [T][ceil(R / 32)]: bit (row & 31) of word row >> 5 = the slot-30 flag of (day, row)
+        R = ct.S_w * ct.Y
+        gw = (R + 31) // 32
+        g = np.zeros((ct.T, gw * 32), np.uint8)
+        g[:, :R] = ct.X[:, :, SLOT_GATE] > 0.5
+        bits = np.packbits(g.reshape(ct.T, gw, 32), axis=2, bitorder="little").view(np.uint32).reshape(ct.T, gw)
+        self.gate_bits = t(bits)
+        s.gate_bits, s.gate_words = self.gate_bits.data_ptr(), gw
         self.struct = s
