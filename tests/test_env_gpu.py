@@ -159,7 +159,8 @@ def test_vector_env_vs_oracle_seeded(dev, n, augment, adversarial, kernel):
     env.close()
 
 
-@pytest.mark.parametrize("n,write_obs", [(64, True), (1000 + 37, True), (4096 + 5, False), (33, True)])
+@pytest.mark.parametrize("n,write_obs", [(64, True), (1000 + 37, True), (4096 + 5, False), (33, True), (1, True),
+                                         (63, True), (65, False), (129, True), (32, True), (31, False)])
 def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     """The 64-envs-per-wave kernel against the 4-lanes-per-env kernel on the same batch: integer state and
     observations identical, rewards equal up to the order of the fp64 additions; ragged tails (n not a
