@@ -22,6 +22,7 @@ ap.add_argument("--kernels", default="auto,classic")
 ap.add_argument("--steps", type=int, default=306)
 ap.add_argument("--num-envs", type=int, default=1 << 20)
 ap.add_argument("--tag", default="")
+ap.add_argument("--pool", type=int, default=8, help="number of distinct action tensors cycled through")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -34,7 +35,7 @@ county = rng.integers(0, ct.S, n)
 base = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
             sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 12, n))
 g = torch.Generator(device=dev).manual_seed(1)
-pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
+pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(args.pool)] * (8 // args.pool)
 ones = [torch.ones(n, dtype=torch.int32, device=dev)] * 8
 
 

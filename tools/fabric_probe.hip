@@ -1,0 +1,183 @@
+// fabric_probe.hip -- what the MI355X memory side delivers for the step kernel's two traffic classes, alone and
+// together, with no env arithmetic at all ("the saturated resource"):
+//   stream : per env 28 B read (12 + 12 + 4, three coalesced streams) and 133 B written (116 B observation row with
+//            non-temporal 16-B stores, 12 + 4 + 1 B state / reward / done) -- the step's compulsory bytes
+//   gather : per env one random 128-B line of a 19 MB table (8 lanes x 16 B, like the coefficient-row gather) and one
+//            128-B line of a 1 MB table (the day slice), reduced to one float so the loads cannot be dropped
+//   both   : one kernel doing both per env (what k_step64 does, minus the arithmetic)
+// Build + run (no torch):  hipcc --offload-arch=gfx950 -O3 tools/fabric_probe.hip -o /tmp/fabric_probe && /tmp/fabric_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct u3 { uint32_t a, b, c; };
+
+template <bool STREAM, bool GATHER>
+__global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc, const int32_t *act, u3 *hot_out,
+                                                  float *reward, uint8_t *done, float *obs, const float4 *W,
+                                                  const float4 *X, const uint32_t *wrow, const uint32_t *xrow, int64_t n) {
+  const int64_t n_raw = n;
+#ifdef PROBE_DAYS
+  X += (size_t)(n >> 40) * 8206 * 8;  // day slice in the upper bits of n (keeps the signature)
+  n &= (1ll << 40) - 1;
+#endif
+  __shared__ float tile[4][32 * 32];
+#ifdef PROBE_LDS_PAD   // caps the occupancy like k_step64's register count does (-DPROBE_LDS_PAD=bytes)
+  __shared__ float pad[PROBE_LDS_PAD / 4];
+  if (n < 0) pad[threadIdx.x] = 0.f;
+#endif
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t env0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (env0 >= n) return;
+  const uint32_t e = (uint32_t)(env0 + lane);
+  float acc = 0.0f;
+  u3 h = {0, 0, 0}, c = {0, 0, 0};
+  int32_t a = 0;
+  if (STREAM) { h = hot[e]; c = stepc[e]; a = act[e]; }
+  const int p = lane & 7, g = lane >> 3;
+#ifdef PROBE_DEP  // like k_step64: the gather indices are part of the streamed state (lane = env) and reach the
+                  // 8-lanes-per-row mapping through LDS, so the gathers wait for the state loads
+  __shared__ uint2 desc[4][64];
+  desc[wave][lane] = make_uint2(c.b, c.c);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  for (int pass = 0; pass < 2; ++pass) {
+    float4 x[4], w[4];
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t j = (uint32_t)env0 + pass * 32 + r * 8 + g;
+      x[r] = make_float4(1.f, 2.f, 3.f, 4.f);
+#ifdef PROBE_RANDOM_DATA  // stream-only mode too writes values that do not repeat
+      {
+        uint32_t q = (j * 8u + (uint32_t)p) * 2654435761u + (uint32_t)(n_raw >> 40) * 40503u;
+        q ^= q >> 15; q *= 2246822519u; q ^= q >> 13;
+        x[r] = make_float4(__uint_as_float(0x3F800000u | (q & 0x7FFFFFu)), __uint_as_float(0x3F800000u | ((q >> 3) & 0x7FFFFFu)),
+                           __uint_as_float(0x3F800000u | ((q >> 6) & 0x7FFFFFu)), __uint_as_float(0x3F800000u | ((q >> 9) & 0x7FFFFFu)));
+      }
+#endif
+      w[r] = x[r];
+      if (GATHER) {
+#ifdef PROBE_DEP
+        const uint2 dd = desc[wave][pass * 32 + r * 8 + g];
+        x[r] = X[dd.x * 8 + p];
+        w[r] = W[dd.y * 16 + p];
+#else
+        x[r] = X[xrow[j] * 8 + p];  // xrow / wrow are read as 8-lane broadcasts (the real kernel takes them from LDS)
+        w[r] = W[wrow[j] * 16 + p];
+#endif
+      }
+    }
+    for (int r = 0; r < 4; ++r) {
+#ifdef PROBE_F64  // the step kernel's arithmetic: two 4-term fp64 chains and an 8-lane fp64 all-reduce per env
+      {
+        double zb = (double)x[r].x * (double)w[r].x, ze = (double)x[r].x * (double)w[r].y;
+        zb = fma((double)x[r].y, (double)w[r].y, zb); ze = fma((double)x[r].y, (double)w[r].z, ze);
+        zb = fma((double)x[r].z, (double)w[r].z, zb); ze = fma((double)x[r].z, (double)w[r].w, ze);
+        zb = fma((double)x[r].w, (double)w[r].w, zb); ze = fma((double)x[r].w, (double)w[r].x, ze);
+        for (int m = 1; m < 8; m <<= 1) {
+          zb += __shfl_xor(zb, m);
+          ze += __shfl_xor(ze, m);
+        }
+        acc += __builtin_amdgcn_rcpf(1.0f + __expf(-(float)zb)) * __builtin_amdgcn_rcpf(1.0f + __expf(-(float)ze));
+      }
+#else
+      acc += x[r].x * w[r].x + x[r].y * w[r].y + x[r].z * w[r].z + x[r].w * w[r].w;
+#endif
+      if (STREAM) {
+        float *t = tile[wave] + (r * 8 + g) * 29 + p * 4;
+        if (p < 7) { t[0] = x[r].x; t[1] = x[r].y; t[2] = x[r].z; t[3] = x[r].w; } else t[0] = x[r].x;
+      }
+    }
+    if (STREAM) {
+      __builtin_amdgcn_wave_barrier();
+      float *dst = obs + (env0 + pass * 32) * 29;
+      for (int c0 = 0; c0 < 256; c0 += 64) {
+        const int ch = c0 + lane;
+        if (ch < 232) __builtin_nontemporal_store(reinterpret_cast<const v4f *>(tile[wave])[ch], reinterpret_cast<v4f *>(dst) + ch);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // lane = env outputs
+  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+  if (STREAM) {
+    h.a += (uint32_t)a; h.c = __float_as_uint(acc + __uint_as_float(c.a) + (float)c.b);
+    hot_out[e] = h;
+    reward[e] = acc;
+    done[e] = (uint8_t)(h.b & 1u);
+  } else if (acc == 123456.789f) {
+    reward[e] = acc;  // keeps the gathers alive without writing
+  }
+}
+
+int main() {
+  const int64_t n = 1 << 20;
+  const int S = 74600, R = 8206;  // coefficient rows (x 256 B) and day-slice rows (x 128 B)
+  u3 *hot, *stepc, *hot_out; int32_t *act; float *reward, *obs; uint8_t *done; float4 *W, *X; uint32_t *wrow, *xrow;
+  CHECK(hipMalloc(&hot, n * 12)); CHECK(hipMalloc(&stepc, n * 12)); CHECK(hipMalloc(&hot_out, n * 12));
+  CHECK(hipMalloc(&act, n * 4)); CHECK(hipMalloc(&reward, n * 4)); CHECK(hipMalloc(&done, n));
+  CHECK(hipMalloc(&obs, n * 29 * 4)); CHECK(hipMalloc(&W, (size_t)S * 256)); CHECK(hipMalloc(&X, (size_t)R * 128 * 153));
+  CHECK(hipMalloc(&wrow, n * 4)); CHECK(hipMalloc(&xrow, n * 4));
+  CHECK(hipMemset(hot, 0, n * 12)); CHECK(hipMemset(stepc, 0, n * 12)); CHECK(hipMemset(act, 0, n * 4));
+  CHECK(hipMemset(W, 0, (size_t)S * 256)); CHECK(hipMemset(X, 0, (size_t)R * 128 * 153));
+#ifdef PROBE_RANDOM_DATA  // random table values instead of zeros (arithmetic on zeros draws less power: clocks differ)
+  {
+    const size_t nx = (size_t)R * 32 * 153, nw = (size_t)S * 64;
+    float *hb = (float *)malloc((nx > nw ? nx : nw) * 4);
+    uint64_t q = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < nx; ++i) { q ^= q << 13; q ^= q >> 7; q ^= q << 17; hb[i] = (float)((q >> 40) * (1.0 / 16777216.0)); }
+    CHECK(hipMemcpy(X, hb, nx * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < nw; ++i) { q ^= q << 13; q ^= q >> 7; q ^= q << 17; hb[i] = (float)((q >> 40) * (1.0 / 16777216.0)) - 0.5f; }
+    CHECK(hipMemcpy(W, hb, nw * 4, hipMemcpyHostToDevice));
+    free(hb);
+  }
+#endif
+  uint32_t *hw = (uint32_t *)malloc(n * 4), *hx = (uint32_t *)malloc(n * 4);
+  uint64_t s = 88172645463325252ull;
+  for (int64_t i = 0; i < n; ++i) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17; hw[i] = (uint32_t)(s % S);
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17; hx[i] = (uint32_t)(s % R);
+  }
+  for (int mode = 0; mode < 2; ++mode) {  // 0: uniform rows (configs[3]-like), 1: rows of the first 25 000 only (configs[2]-like)
+    if (mode == 1) for (int64_t i = 0; i < n; ++i) hw[i] %= 25000;
+    CHECK(hipMemcpy(wrow, hw, n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(xrow, hx, n * 4, hipMemcpyHostToDevice));
+    {
+      u3 *hs = (u3 *)malloc(n * 12);
+      for (int64_t i = 0; i < n; ++i) { hs[i].a = 0; hs[i].b = hx[i]; hs[i].c = hw[i]; }
+      CHECK(hipMemcpy(stepc, hs, n * 12, hipMemcpyHostToDevice));
+      free(hs);
+    }
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)(n / 256)), block(256);
+    const char *names[3] = {"stream only (161 B/env compulsory)", "gather only (2 x 128-B lines/env)", "stream + gather"};
+    for (int k = 0; k < 3; ++k) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        for (int it = 0; it < 100; ++it) {
+#ifdef PROBE_DAYS
+          const int64_t n = ((int64_t)(it % 153) << 40) | (1 << 20);
+#endif
+#ifdef PROBE_INPLACE  // like the env: the state words are updated in place
+          u3 *hin = hot, *hout = hot;
+#else
+          u3 *hin = (it & 1) ? hot_out : hot, *hout = (it & 1) ? hot : hot_out;
+#endif
+          if (k == 0) hipLaunchKernelGGL((k_probe<true, false>), grid, block, 0, 0, hin, stepc, act, hout, reward, done, obs, W, X, wrow, xrow, n);
+          if (k == 1) hipLaunchKernelGGL((k_probe<false, true>), grid, block, 0, 0, hin, stepc, act, hout, reward, done, obs, W, X, wrow, xrow, n);
+          if (k == 2) hipLaunchKernelGGL((k_probe<true, true>), grid, block, 0, 0, hin, stepc, act, hout, reward, done, obs, W, X, wrow, xrow, n);
+        }
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      printf("%s %-36s: %6.2f us per launch (back to back, incl. the launch boundary)\n",
+             mode ? "[rows < 25 000]" : "[uniform rows ]", names[k], best * 10.0f);
+    }
+  }
+  return 0;
+}

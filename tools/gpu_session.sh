@@ -26,7 +26,7 @@ for step in "$@"; do
       for flags in "${FL[@]}"; do
         echo "=== W2A_CXXFLAGS=$flags" | tee -a gpurun_out/ab2.log
         W2A_CXXFLAGS="$flags" python -c "from weather2alert_amd import build; build.build_lib(force=True)" || exit 1
-        timeout -k 10 300 python bench.py --no-cpu-baseline --steps 612 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iid %.2f us  always-alert %.2f us  sorted %.2f us  e2e %.2f G/s' % (d['roofline']['avg_launch_us'], d['always_alert_policy']['kernel_us'], d['sorted_episode_order']['kernel_us'], d['value']/1e9))" | tee -a gpurun_out/ab2.log
+        timeout -k 10 300 python bench.py --no-cpu-baseline --steps 612 ${AB_BENCH_ARGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('iid %.2f us  always-alert %.2f us  sorted %.2f us  e2e %.2f G/s' % (d['roofline']['avg_launch_us'], d['always_alert_policy']['kernel_us'], d['sorted_episode_order']['kernel_us'], d['value']/1e9))" | tee -a gpurun_out/ab2.log
       done
       python -c "from weather2alert_amd import build; build.build_lib(force=True)" ;;
     benchall)

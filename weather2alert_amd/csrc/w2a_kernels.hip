@@ -221,8 +221,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
   if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
-    // the lean 64-envs-per-wave form (w2a_step64.hip.h); tiles of BLOCK envs, a multiple of 8 workgroups
-    const int64_t tiles = (env->n + BLOCK - 1) / BLOCK;
+    // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
+    // multiple of 8 workgroups
+    const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
+    const int64_t tiles = (env->n + per_wg - 1) / per_wg;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
     if (given) {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);

@@ -91,36 +91,18 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 #ifndef W2A_S64_MIN_WAVES
 #define W2A_S64_MIN_WAVES 4  // waves/SIMD the kernel is compiled for (<= 128 VGPRs)
 #endif
+#ifndef W2A_S64_TILES
+#define W2A_S64_TILES 1  // consecutive 64-env tiles per wave (2 and 4, with the next tile's state loads in flight, measured slower)
+#endif
+// One 64-env tile of one wave, phases A..C, from the tile's already loaded state words and action.
 // REWARD_GIVEN: a.reward already holds today's reward (w2a_posterior_mean_reward ran on the same state and actions):
 // no coefficient gather and no logits here, the rest of env.py:238-262 as usual.
 template <bool WRITE_OBS, bool REWARD_GIVEN>
-__global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
-  __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  S64Wave &sw = s_w[wave];
-  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
-  const int64_t wave_env0 = ((int64_t)lb * S64_WAVES + wave) * S64_ENVS;
-  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no workgroup barrier is used below
-
+__device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const int lane, const int64_t wave_env0,
+                                         const bool valid, const uint32_t e, const u3 h, const u3 c, const int32_t act,
+                                         const int4 so) {
   // ---------------------------------------------------------------- phase A: lane = env
-  const int64_t env = wave_env0 + lane;
-  const bool valid = env < a.n;
-  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: surplus lanes shadow the last env, never store
-#if W2A_S64_NT_STATE & 1
-  const v3u hv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.hot3[e]));
-  u3 h; h.a = hv.x; h.b = hv.y; h.c = hv.z;
-#else
-  const u3 h = a.st.hot3[e];
-#endif
-#if W2A_S64_NT_STATE & 2
-  const v3u cv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.stepc[e]));
-  u3 c; c.a = cv.x; c.b = cv.y; c.c = cv.z;
-#else
-  const u3 c = a.st.stepc[e];
-#endif
-  const Day d = derive_day(h, c, load_action(a, e));
+  const Day d = derive_day(h, c, act);
   const uint32_t t = d.t, used2 = d.used2, hist2 = d.hist2, streak = d.streak, ndays = d.ndays;
   const uint32_t actual = d.actual, atb = d.atb, st_bits = d.st_bits;
   const int32_t budget = d.budget;
@@ -147,8 +129,6 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   // ---------------------------------------------------------------- phase B: 8 lanes = one 128-B row
   const int p = lane & 7;   // float4 of the row owned by this lane
   const int g = lane >> 3;  // row group: env j = pass * 32 + round * 8 + g of the wave
-  int4 so = make_int4(-1, -1, -1, -1);
-  if (WRITE_OBS) so = reinterpret_cast<const int4 *>(a.slot_obs)[p];
   const int n_obs = a.tb.n_obs;
   const bool write_me = valid && !done;  // a finished env keeps its stale observation (env.py:257-262, Q6)
 #pragma unroll 1
@@ -166,7 +146,11 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       wb[r] = we[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!REWARD_GIVEN) {
         wb[r] = a.tb.W[wq + p];
-        if (need[r]) we[r] = a.tb.W[wq + ROWF / 4 + p];
+        // branch-free: groups that do not need the effectiveness row re-request their baseline line (already in
+        // flight, no extra fabric traffic) and the value is dropped below. A conditional load would make the
+        // compiler wait for it (s_waitcnt vmcnt(0)) at the end of its branch, before the next round's loads issue:
+        // one exposed memory round trip per round with an alert.
+        we[r] = a.tb.W[wq + (need[r] ? ROWF / 4 : 0) + p];
       }
     }
 #pragma unroll
@@ -188,6 +172,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       if (__any(need[r]))  // wave-uniform: most rounds have no alert today (eff * actual = 0 whatever eff is)
 #endif
       {
+        // groups without need carry their baseline row here: harmless, their ze is never used (phase C)
         ze = x0 * (double)we[r].x;
         ze = fma(x1, (double)we[r].y, ze);
         ze = fma(x2, (double)we[r].z, ze);
@@ -257,7 +242,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   }
 
   // ---------------------------------------------------------------- phase C: lane = env
-  if (!valid) return;
+  if (valid) {
   float r;
   if (REWARD_GIVEN) {
     r = a.reward[e];
@@ -285,6 +270,68 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
 #endif
   if (done && a.last_return) a.last_return[e] = ret;
   if (st_bits) atomicOr(a.status, (int)st_bits);
+  }
+}
+
+__device__ __forceinline__ void s64_load_state(const StepArgs &a, uint32_t e, u3 &h, u3 &c, int32_t &act) {
+#if W2A_S64_NT_STATE & 1
+  const v3u hv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.hot3[e]));
+  h.a = hv.x; h.b = hv.y; h.c = hv.z;
+#else
+  h = a.st.hot3[e];
+#endif
+#if W2A_S64_NT_STATE & 2
+  const v3u cv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.stepc[e]));
+  c.a = cv.x; c.b = cv.y; c.c = cv.z;
+#else
+  c = a.st.stepc[e];
+#endif
+  act = load_action(a, e);
+}
+
+// A wave owns W2A_S64_TILES consecutive 64-env tiles. The first memory hop of a tile (its three coalesced state /
+// action streams, 28 B per env) has few bytes in flight and a full memory round trip of latency; requesting the
+// NEXT tile's words before the current tile's phases run takes that hop off the wave's critical path for every
+// tile but the first (7 more VGPRs). Measured: DESIGN.md §4.
+template <bool WRITE_OBS, bool REWARD_GIVEN>
+__global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
+  __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  S64Wave &sw = s_w[wave];
+  const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
+  const int64_t wave_env0 = ((int64_t)lb * S64_WAVES + wave) * (S64_ENVS * W2A_S64_TILES);
+  if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no workgroup barrier is used below
+  u3 hn, cn;
+  int32_t an;
+  {
+    const int64_t env = wave_env0 + lane;
+    s64_load_state(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
+  }
+  // slot -> observation column of the 4 row slots this lane owns in the row phase; requested together with the
+  // state words so that its latency is not exposed in front of the gathers
+  int4 so = make_int4(-1, -1, -1, -1);
+  if (WRITE_OBS) so = reinterpret_cast<const int4 *>(a.slot_obs)[lane & 7];
+#pragma unroll 1
+  for (int i = 0; i < W2A_S64_TILES; ++i) {
+    const int64_t env0 = wave_env0 + (int64_t)i * S64_ENVS;
+    if (env0 >= a.n) break;  // wave-uniform
+    const int64_t env = env0 + lane;
+    const bool valid = env < a.n;
+    const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));  // clamp: surplus lanes shadow the last env, never store
+    const u3 h = hn, c = cn;
+    const int32_t act = an;
+    if (i + 1 < W2A_S64_TILES && env0 + S64_ENVS < a.n) {
+      const int64_t en = env + S64_ENVS;
+      s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
+    }
+    s64_tile<WRITE_OBS, REWARD_GIVEN>(a, sw, lane, env0, valid, e, h, c, act, so);
+    // the per-wave LDS record is rewritten by the next tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 #endif  // W2A_STEP64_HIP_H
