@@ -86,14 +86,15 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     const float4 *wp = a.tb.W + wrow * (2 * ROWF / 4) + l * QUADS;
     float4 wb[QUADS], we[QUADS];
     // The effectiveness logit only enters the reward through eff * actual (env.py:221): without an alert today
-    // its coefficient row is not fetched at all (most env-days: alerts are budget-limited) -- half the
-    // coefficient traffic. The lanes of such envs are masked out of the load; the reward is bit-identical.
-    const bool need_eff = actual != 0u;
+    // its coefficient row is not fetched (most env-days: alerts are budget-limited) -- half the coefficient
+    // traffic. Branch-free: such groups re-request their baseline row (already in flight) and the resulting logit
+    // is multiplied by actual = 0; a conditional load would be waited for at the end of its branch, before the
+    // arithmetic of anybody else in the wave could start. The reward is bit-identical.
+    const int eff_off = (actual != 0u) ? ROWF / 4 : 0;
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) {
       wb[q] = ld_w(wp + q);
-      we[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (need_eff) we[q] = ld_w(wp + ROWF / 4 + q);
+      we[q] = ld_w(wp + eff_off + q);
     }
     // env.py:207-217: two 28-term dot products, fp64 accumulation
     zb = 0.0;
