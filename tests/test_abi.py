@@ -85,3 +85,19 @@ def test_header_is_plain_c_and_links(lib, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert f"sizeof(w2a_tables)={C.sizeof(_ffi.Tables)}" in r.stdout
+
+
+def test_probe_programs_build(lib, tmp_path):
+    """The two stand-alone measurement programs behind DESIGN.md §5 (tools/fabric_probe.hip: the step's traffic
+    pattern without env logic; tools/abi_probe.cpp: the step kernels through the C ABI from a C++ host) still
+    cross-compile for gfx950 -- the second one against the current header and library."""
+    import subprocess
+
+    hipcc = build.hipcc_path()
+    libdir = os.path.dirname(_ffi.lib_path())
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-DPROBE_F64", "-DPROBE_DEP", "-DPROBE_DAYS",
+                    "-DPROBE_RANDOM_DATA", os.path.join(ROOT, "tools", "fabric_probe.hip"), "-o",
+                    str(tmp_path / "fabric_probe")], check=True, capture_output=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tools", "abi_probe.cpp"), "-L", libdir, "-lw2a", f"-Wl,-rpath,{libdir}", "-o",
+                    str(tmp_path / "abi_probe")], check=True, capture_output=True)
