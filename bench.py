@@ -436,6 +436,16 @@ def main():
                 traffic = ent
             elif ent is not None:
                 traffic_note = "profiles/traffic_latest.json was collected on other kernel sources: not reported"
+        # the memory side's measured rate for this access pattern without any env logic (static reference from
+        # profiles/, 1 048 576 envs): kernel time / probe time says how close the kernel is to what the chip delivers
+        probe = None
+        try:
+            pc = json.load(open(os.path.join(ROOT, "profiles", "probe_ceiling.json"))).get(args.workload)
+            if pc and n == 1048576 and not args.no_obs:
+                probe = {"probe_us": pc["us"], "kernel_over_probe": per_launch_s * 1e6 / pc["us"],
+                         "source": "profiles/r02/fabric_probe.log (tools/fabric_probe.hip, random data)"}
+        except Exception:  # noqa: BLE001
+            probe = None
         out = {
             "metric": "env_steps_per_sec", "value": total_env_steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
@@ -466,6 +476,7 @@ def main():
                          {k: traffic.get(k) for k in ("read_bytes_per_launch", "write_bytes_per_launch",
                                                       "kernel_avg_us", "src_sha", "commit", "profile")},
                          "traffic_note": traffic_note, "kernel_src_sha": src_sha,
+                         "probe_ceiling": probe,
                          "frac_of_measured_copy_bw": achieved / 6290.0,
                          "survey_8d_model": {"bytes_per_env_step": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"],
                                              "gbs": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"] * n
