@@ -539,6 +539,22 @@ def main():
                 "note": "per step: [envs of a column x 32 slots] x [32 x 2 heads x 100 draws] on v_mfma_f64_16x16x4_f64, "
                         "f32 sigmoid / gate / mean epilogue; time includes the step kernel that consumes the reward"}
             e4.close()
+            # (4) the single-GPU rate of the multi-GPU default workload (configs[4] = nn_full_medicare_all shape), so
+            # that `--gpus N` values have their own N = 1 denominator in this file
+            if args.workload == "configs2":
+                w4, n4, aug4, _ = WORKLOADS["configs4"]
+                sd4 = synth.make_synth(w4, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
+                                       extra_confounder_fips=60)
+                e5 = HeatAlertVecEnv(n4, tables=tables.compile_from_synth(sd4), device=device,
+                                     similar_climate_counties=aug4, write_obs=not args.no_obs)
+                e5.reset(seed=args.seed)
+                timed_steps(e5, pool, 10, torch)
+                kms, kwall = timed_steps(e5, pool, 130, torch)
+                out["configs4_single_gpu"] = {
+                    "kernel_us": kms * 1e3 / 130, "value": n4 * 130 / kwall, "unit": "env-steps/s",
+                    "note": "python bench.py --gpus N (N > 1) runs this workload per GPU: compare its values with "
+                            "N x this one, not with the configs[2] headline above"}
+                e5.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
             procs = min(16, os.cpu_count() or 1)
