@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 4
+#define W2A_ABI_VERSION 5
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -175,12 +175,12 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
  * instead of the one draw of the episode. One grouped fp64-MFMA GEMM per step: per column
  * [envs x 32 slots] * [32 slots x 2 heads x n_samples draws], sigmoid / gate / mean epilogue.
  *   w2a_group_by_column        after EVERY reset: sorts the env ids by coefficient column into `workspace`
- *                              (caller-owned, w2a_group_workspace_bytes(num_envs), 256-B aligned, must stay alive
+ *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples), 256-B aligned, must stay alive
  *                              while w2a_posterior_mean_reward is used);
  *   w2a_posterior_mean_reward  before w2a_step(..., W2A_STEP_REWARD_GIVEN) with the SAME actions: writes
  *                              reward [num_envs] f32 from the pre-step state. Same budget gate as the step
  *                              (env.py:242-246): an alert attempted at budget counts as no alert. */
-size_t w2a_group_workspace_bytes(int64_t num_envs);
+size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples);
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream);
 

@@ -860,15 +860,17 @@ def test_other_schema_parity(dev):
         env.close()
 
 
-@pytest.mark.parametrize("n,n_fips,n_samples,augment,adversarial", [
-    (3000 + 5, 48, 12, True, False), (37, 30, 100, False, False), (4096, 746, 100, True, False),
-    (2048 + 9, 40, 20, True, True)])
-def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial):
+@pytest.mark.parametrize("n,n_fips,n_samples,augment,adversarial,tail", [
+    (3000 + 5, 48, 12, True, False, False), (37, 30, 100, False, False, False), (4096, 746, 100, True, False, False),
+    (2048 + 9, 40, 20, True, True, False), (1500 + 3, 48, 12, True, False, True)])
+def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial, tail):
     """reward_mode='posterior_mean' (legacy eval mode, _deprecated/env.py:332-342, on today's reward form): the
     grouped fp64-MFMA GEMM + sigmoid/mean epilogue against the oracle's mean over every posterior draw; everything
     but the reward (observations, integer state, termination) equals the sampled-reward env. Ragged draw counts
     (12: a partial 16-column MFMA tile), tiles that span many coefficient columns (n = 37), the full 746-column
-    table, and augmentation (Q8: the coefficient column differs from the weather county)."""
+    table, and augmentation (Q8: the coefficient column differs from the weather county). 'tail' gives slot 31 (always
+    zero in the feature rows) a coefficient: w2a_create then selects the kernel that contracts all 32 slots instead of
+    slots 0..27 + bias, and the reward must not change."""
     from weather2alert_amd import HeatAlertVecEnv
 
     # adversarial: unscaled N(0,1) coefficients (logit terms up to ~150 with cancellation): the fp64 MFMA holds the bar
@@ -876,6 +878,8 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
                           extra_confounder_fips=5, weight_scale=None if adversarial else synth.DEFAULT_SCALE,
                           weight_sigma=1.0 if adversarial else 0.3)
     ct = tables.compile_from_synth(sd)
+    if tail:
+        ct.W[..., 31] = 0.5
     rd = O.RefData.from_synth(sd)
     V = O.VectorOracle(rd, sd.fips_weather, sd.years, reward_mode="posterior_mean")
     rng = np.random.default_rng(n)
@@ -911,6 +915,37 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
     print(f"posterior mean n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
     pm.close()
     sm.close()
+
+
+def test_posterior_mean_with_a_coefficient_on_the_25th_table_column(dev):
+    """include/w2a.h allows a coefficient on slot 28 (the 25th table-sourced column; none in the reference schema, where
+    that column is 'significance'). With ONE posterior draw the mean over draws is the sampled reward, so the 32-slot
+    variant of the GEMM kernel is checked against the step kernel's own 32-slot dot product."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    n = 2000 + 7
+    sd = synth.make_synth("linear", n_fips=36, years=[2006, 2007], n_samples=1, seed=23, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    assert np.count_nonzero(ct.X[..., 28]) > 0
+    ct.W[..., 28] = np.random.default_rng(5).normal(0, 0.2, ct.W.shape[:-1]).astype(np.float32)
+    rng = np.random.default_rng(n)
+    ep = _random_tuples(ct, n, rng, True)
+    pm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean")
+    sm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
+    ref = HeatAlertVecEnv(n, tables=tables.compile_from_synth(sd), device=dev, autoreset="disabled")
+    for e in (pm, sm, ref):
+        e.reset(options={"episodes": ep})
+    differs = False
+    for t in range(60):
+        at = torch.as_tensor((rng.random(n) < 0.3).astype(np.int32), device=dev)
+        _, r, _, _, _ = pm.step(at)
+        _, r_s, _, _, _ = sm.step(at)
+        _, r_0, _, _, _ = ref.step(at)
+        assert (r - r_s).abs().max().item() <= 2e-6, t
+        differs = differs or (r_s - r_0).abs().max().item() > 1e-3
+    assert differs  # the extra coefficient does reach the reward
+    for e in (pm, sm, ref):
+        e.close()
 
 
 def test_posterior_mean_lockstep_autoreset_and_guards(dev):

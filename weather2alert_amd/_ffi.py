@@ -13,7 +13,7 @@ ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE = 1, 2, 8, 16, 32
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -106,7 +106,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_sort_episodes.restype = C.c_int
     lib.w2a_sort_episodes.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_group_workspace_bytes.restype = C.c_size_t
-    lib.w2a_group_workspace_bytes.argtypes = [i64]
+    lib.w2a_group_workspace_bytes.argtypes = [i64, C.c_int32, C.c_int32]
     lib.w2a_group_by_column.restype = C.c_int
     lib.w2a_group_by_column.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_posterior_mean_reward.restype = C.c_int

@@ -153,7 +153,10 @@ struct w2a_env {
   int32_t obs_slot_host[ROWF];
   const uint32_t *perm;  // env ids sorted by coefficient column (w2a_group_by_column), valid until the next reset
   uint4 *prep;           // per-step scratch of the posterior-mean path, inside the same workspace
+  const uint32_t *inv;   // sorted position of every env, in the same workspace
+  const double *wd;      // fp64 copy of W scaled by -log2(e), in the same workspace
   int perm_valid;
+  int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };
 
 static thread_local char g_err[512] = "";

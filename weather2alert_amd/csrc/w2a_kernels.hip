@@ -130,8 +130,16 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: header upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
   int64_t blocks = (num_envs + 255) / 256;
   hipLaunchKernelGGL(k_init_state, dim3((unsigned)blocks), dim3(256), 0, 0, h->st, num_envs);
+  // header word 32: scratch for the one-off scan of the coefficient rows (see k_scan_tail_slots)
+  int32_t *scan_flag = reinterpret_cast<int32_t *>(state) + ROWF;
+  const int64_t w_rows = (int64_t)t->S * t->n_samples * 2;
+  hipError_t e4 = hipMemset(scan_flag, 0, sizeof(int32_t));
+  hipLaunchKernelGGL(k_scan_tail_slots, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, 0, h->tb.W, w_rows, scan_flag);
   hipError_t e3 = hipDeviceSynchronize();
-  if (e3 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernel failed: %s", hipGetErrorString(e3)); }
+  int32_t tail_used = 1;
+  if (e3 == hipSuccess && e4 == hipSuccess) e3 = hipMemcpy(&tail_used, scan_flag, sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e3 != hipSuccess || e4 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernels failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : e4)); }
+  h->w_tail_used = tail_used;
   *out = h;
   return W2A_OK;
 }
@@ -298,20 +306,24 @@ static size_t cub_group_bytes(int64_t n) {
   return b;
 }
 
-size_t w2a_group_workspace_bytes(int64_t num_envs) {
-  if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
-  return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + align256(cub_group_bytes(num_envs));
+static size_t wd_bytes(int32_t S, int32_t n_samples) { return align256((size_t)S * n_samples * 2 * ROWF * sizeof(double)); }
+
+size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples) {
+  if (num_envs <= 0 || num_envs > (1ll << 27) || S <= 0 || n_samples <= 0) return 0;
+  return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + wd_bytes(S, n_samples) +
+         align256(cub_group_bytes(num_envs));
 }
 
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_group_by_column: NULL argument");
-  if (workspace_bytes < w2a_group_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
+  if (workspace_bytes < w2a_group_workspace_bytes(env->n, env->tb.S, env->tb.n_samples)) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace must be 256-B aligned");
   const size_t n = (size_t)env->n;
   char *p = (char *)workspace;
   uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first two: stay in use after the call
   env->prep = (uint4 *)p;          p += align256(16 * n);
-  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
+  double *wd = (double *)p;        p += wd_bytes(env->tb.S, env->tb.n_samples);
+  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);  // sort keys, then the inverse permutation (stays in use)
   uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
   size_t cub_bytes = cub_group_bytes(env->n);
@@ -321,6 +333,16 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   int bits = 1;
   while ((1 << bits) < env->tb.S) ++bits;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, perm, (int)n, 0, bits, s));
+  // fp64 copy of the coefficient rows, scaled by -log2(e), for the scalar-operand form of the reward kernel
+  const int64_t w_count = (int64_t)env->tb.S * env->tb.n_samples * 2 * ROWF;
+  hipLaunchKernelGGL(k_pm_wd, dim3((unsigned)((w_count + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float *>(env->tb.W), wd, w_count);
+  HIP_TRY(hipGetLastError());
+  env->wd = wd;
+  // sorted position of every env, kept in the first key buffer
+  hipLaunchKernelGGL(k_group_inverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, k_in, env->n);
+  HIP_TRY(hipGetLastError());
+  env->inv = k_in;
   env->perm = perm;
   env->perm_valid = 1;
   return W2A_OK;
@@ -335,12 +357,19 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: not available with corrected-semantics flags");
   PosteriorArgs a;
   memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.st = env->st; a.perm = env->perm; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
-  a.reward = reward; a.status = env->status; a.n = env->n;
+  a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
+  a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd;
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
+#if W2A_PM_MATRIX
   const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
-  hipLaunchKernelGGL(k_posterior_mean, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_posterior_mean<7>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+#else
+  const unsigned grid = (unsigned)(((env->n + PMV_THREADS - 1) / PMV_THREADS + 7) / 8 * 8);
+  if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean_v<8>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_posterior_mean_v<7>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
+#endif
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }

@@ -5,6 +5,8 @@
 #ifndef W2A_POSTERIOR_HIP_H
 #define W2A_POSTERIOR_HIP_H
 
+#include <type_traits>
+
 // For env e with coefficient column c:   reward_e = mean_s  -(1000/152) * sigmoid(zb_s) * (1 - sigmoid(ze_s) * gate * actual)
 //     zb_s = sum_k x_k * Wb[c][s][k],   ze_s = sum_k x_k * We[c][s][k]          (k over the 32 row slots)
 // i.e. per column c one dense contraction  D_c [N_c envs][2 * n_samples] = A_c [N_c][32] * B_c [32][2 * n_samples]
@@ -13,8 +15,13 @@
 //   * the workgroup stages B_c (both heads, all draws: 25.6 KB of f32) in LDS once per column segment;
 //   * each of its 4 waves owns 4 row tiles of 16: A fragments = the env's feature row of the day with the run-time slots
 //     patched in (the same derive_day()/runtime_fields() as the step kernel), converted f32 -> f64 in registers;
-//   * per 16-draw tile 8 + 8 v_mfma_f64_16x16x4_f64 (K = 32 slots; products of f32 values are exact in fp64, so
-//     the logits carry ~1e-16 relative error, as in the step kernels);
+//   * the rows of a column segment are re-ordered inside the workgroup so that the few with an open gate AND an alert
+//     today (the only ones whose reward depends on the effectiveness head, env.py:218-221) sit in its first row
+//     tiles: every other tile runs the baseline head alone;
+//   * per 16-draw tile 7 (+ 7) v_mfma_f64_16x16x4_f64 over slots 0..27, the accumulators starting from the bias
+//     coefficient of the draw (slot 29 holds 1.0 in every row); an 8th k-step (slots 28..31) only for schemas with a
+//     25th table column. Products of f32 values are exact in fp64, so the logits carry ~1e-16 relative error, as in
+//     the step kernels;
 //   * epilogue in the accumulator layout (lane = draw column, 4 rows per lane): f32 sigmoids as in the step
 //     kernels, closed gate = -inf logit, per-row sums over draws in fp64, 16-lane DPP all-reduce, one f32 per env.
 // The step kernel then runs with W2A_STEP_REWARD_GIVEN and does everything else of env.py:238-262.
@@ -22,16 +29,17 @@
 static_assert(PM_ROWS == BLOCK, "one thread per row in the set-up phase");
 #define PM_TILES_PER_WAVE (PM_ROWS / 16 / (BLOCK / 64))
 #define PM_NPAD 112                // draws per staging pass (7 MFMA column tiles)
-#ifndef W2A_PM_EXPERIMENT
-#define W2A_PM_EXPERIMENT 0
+#ifndef W2A_PM_MATRIX
+#define W2A_PM_MATRIX 0            // A/B: 1 = the fp64-MFMA form (k_posterior_mean), 0 = the lane = env form (k_posterior_mean_v)
 #endif
 typedef double pm_double4 __attribute__((ext_vector_type(4)));
 
 struct PosteriorArgs {
   DevTables tb;
   StateArrays st;
-  const uint32_t *perm;  // [n] env ids sorted by coefficient column
-  uint4 *prep;           // [n] per-env record of the day, env order (k_pm_prep -> k_posterior_mean)
+  const uint32_t *inv;   // [n] sorted position of every env (inverse of the env ids sorted by coefficient column)
+  uint4 *prep;           // [n] per-env record of the day in SORTED order (k_pm_prep -> k_posterior_mean*)
+  const double *wd;      // [S * n_samples][2][32] coefficient rows as -log2(e) * W in fp64 (k_pm_wd)
   const void *actions;
   int32_t act_dtype;
   float *reward;
@@ -39,11 +47,12 @@ struct PosteriorArgs {
   int64_t n;
 };
 
-// Per-env record of the day in ENV order (coalesced state / action reads, like phase A of k_step64), so that the
-// GEMM kernel, which walks the envs in column order, gathers ONE 16-B record per env instead of three state words
-// and a feature-row word:  x = float index of the feature row, y = run-time fields packed (alert_lag1 bit 0,
-// alert_streak bits 1..10, alert_2wks bits 11..14, gate * actual bit 15, remaining_budget bits 16..31: budgets
-// up to 65535, checked by the host class), z = coefficient column.
+// Per-env record of the day, computed in ENV order (coalesced state / action reads, like phase A of k_step64) and
+// written to the env's position in the column order (one scattered 16-B store per env: stores do not stall), so the
+// reward kernel, which walks the envs in column order, reads its records coalesced with no dependent gather:
+// x = float index of the feature row, y = run-time fields packed (alert_lag1 bit 0, alert_streak bits 1..10,
+// alert_2wks bits 11..14, gate * actual bit 15, remaining_budget bits 16..31: budgets up to 65535, checked by the
+// host class), z = coefficient column, w = env id.
 __global__ void k_pm_prep(const PosteriorArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
@@ -57,8 +66,13 @@ __global__ void k_pm_prep(const PosteriorArgs a) {
   const uint32_t ga = (d.actual && reinterpret_cast<const float *>(a.tb.X)[xrow + 30] > 0.5f) ? 1u : 0u;
   const uint32_t rem = (uint32_t)min(max((int32_t)rt.z, 0), 65535);
   const uint32_t pk = (uint32_t)rt.x | ((uint32_t)rt.y << 1) | ((uint32_t)rt.w << 11) | (ga << 15) | (rem << 16);
-  a.prep[e] = make_uint4(xrow, pk, W_COL(c.c), 0u);
+  a.prep[a.inv[e]] = make_uint4(xrow, pk, W_COL(c.c), e);
   if (d.st_bits) atomicOr(a.status, (int)d.st_bits);
+}
+
+__global__ void k_group_inverse(const uint32_t *perm, uint32_t *inv, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = (uint32_t)i;
 }
 
 __global__ void k_group_keys(const u3 *stepc, uint32_t *keys, uint32_t *idx, int64_t n) {
@@ -68,48 +82,91 @@ __global__ void k_group_keys(const u3 *stepc, uint32_t *keys, uint32_t *idx, int
   idx[i] = (uint32_t)i;
 }
 
+// Run once by w2a_create: does any coefficient row use slots 28, 30 or 31? (The reference schema's 25th table column,
+// 'significance', is not a reward feature: its slot has no coefficient, and k_posterior_mean then contracts slots
+// 0..27 only.) One thread per 32-float coefficient row.
+__global__ void k_scan_tail_slots(const float4 *W, int64_t rows, int32_t *flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const float4 v = W[i * (ROWF / 4) + ROWF / 4 - 1];  // slots 28..31; 29 is the bias
+  if (v.x != 0.0f || v.z != 0.0f || v.w != 0.0f) atomicOr(flag, 1);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double pm_add_dpp(double v) { return v + dpp_f64<CTRL>(v); }
 
-// the 8 B-operand values of one (head, 16-draw tile) for this lane: slots 4 ks + q, ks = 0..7
-struct PmB { float v[ROWF / 4]; };
-__device__ __forceinline__ PmB pm_load_b(const float (*sBh)[PM_NPAD], int q, int nn) {
-  PmB b;
+// the B-operand values of one (head, 16-draw tile) for this lane: slots 4 ks + q, ks = 0..KS-1, and the draw's bias
+template <int KS>
+struct PmB { float v[KS]; float bias; };
+template <int KS>
+__device__ __forceinline__ PmB<KS> pm_load_b(const float (*sBh)[PM_NPAD], int q, int nn) {
+  PmB<KS> b;
 #pragma unroll
-  for (int ks = 0; ks < ROWF / 4; ++ks) b.v[ks] = sBh[4 * ks + q][nn];
+  for (int ks = 0; ks < KS; ++ks) b.v[ks] = sBh[4 * ks + q][nn];
+  b.bias = sBh[29][nn];
   return b;
 }
 
+// KS = 7: slots 0..27 through the MFMAs, bias as the accumulators' start value (slot 28 unused by the schema, slot 30
+// has a zero coefficient, slot 31 is zero: include/w2a.h). KS = 8: all 32 slots through the MFMAs, start value 0.
+template <int KS>
 __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs a) {
   __shared__ float sB[2][ROWF][PM_NPAD];         // [head][slot][draw]
   __shared__ uint32_t s_col[PM_ROWS];            // coefficient column per row (0xFFFFFFFF: row past the end)
   __shared__ float4 s_rt[PM_ROWS];               // run-time slots 24..27
   __shared__ float s_ga[PM_ROWS];                // gate * actual (0 or 1)
   __shared__ uint32_t s_xrow[PM_ROWS];           // float index of the row's feature row
+  __shared__ uint32_t s_env[PM_ROWS];            // env id of the row (rows are re-ordered inside the workgroup)
   __shared__ double s_sum[PM_ROWS];
+  __shared__ uint32_t s_wga[BLOCK / 64];
+  uint32_t *s_G = reinterpret_cast<uint32_t *>(s_sum);  // [PM_ROWS + 1] during set-up only
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int64_t pos0 = (int64_t)blockIdx.x * PM_ROWS;
   const float *Xf = reinterpret_cast<const float *>(a.tb.X);
   const float *Wf = reinterpret_cast<const float *>(a.tb.W);
-  // ---- per-row set-up: thread r owns sorted position pos0 + r (PM_ROWS == BLOCK)
-  uint32_t my_env = 0;
+  // ---- per-row set-up: thread r loads sorted position pos0 + r (PM_ROWS == BLOCK) ...
   {
     const int64_t pos = pos0 + tid;
-    uint32_t col = 0xFFFFFFFFu, xrow = 0;
+    uint32_t col = 0xFFFFFFFFu, xrow = 0, my_env = 0;
     float4 rt = make_float4(0.f, 0.f, 0.f, 0.f);
-    float ga = 0.0f;
+    uint32_t ga = 0;
     if (pos < a.n) {
-      my_env = a.perm[pos];
-      const uint4 pr = a.prep[my_env];
+      const uint4 pr = a.prep[pos];
+      my_env = pr.w;
       xrow = pr.x;
       col = pr.z;
       rt = make_float4((float)(pr.y & 1u), (float)((pr.y >> 1) & 1023u), (float)(pr.y >> 16),
                        (float)((pr.y >> 11) & 15u));
-      ga = (float)((pr.y >> 15) & 1u);
+      ga = (pr.y >> 15) & 1u;
     }
-    s_col[tid] = col; s_xrow[tid] = xrow; s_rt[tid] = rt; s_ga[tid] = ga; s_sum[tid] = 0.0;
+    // ... and moves it to row p: inside each column segment the rows with gate * actual = 1 first (a stable partition;
+    // s_col is unchanged by it). G[r] = number of such rows before row r.
+    const uint64_t bal = __ballot(ga != 0);
+    const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    s_col[tid] = col;
+    if (lane == 0) s_wga[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t G = before;
+    for (int w = 0; w < wave; ++w) G += s_wga[w];
+    s_G[tid] = G;
+    if (tid == BLOCK - 1) s_G[PM_ROWS] = G + ga;
+    int s_lo = 0, s_hi = tid;            // segment start: first row with this column
+    while (s_lo < s_hi) {
+      const int mid = (s_lo + s_hi) >> 1;
+      if (s_col[mid] < col) s_lo = mid + 1; else s_hi = mid;
+    }
+    int e_lo = tid + 1, e_hi = PM_ROWS;  // segment end: first row with a larger column
+    while (e_lo < e_hi) {
+      const int mid = (e_lo + e_hi) >> 1;
+      if (s_col[mid] > col) e_hi = mid; else e_lo = mid + 1;
+    }
+    __syncthreads();
+    const uint32_t g0 = s_G[s_lo], g_seg = s_G[e_lo] - g0, g_me = G - g0;
+    const uint32_t p = (uint32_t)s_lo + (ga ? g_me : g_seg + ((uint32_t)(tid - s_lo) - g_me));
+    __syncthreads();                     // s_G is s_sum's memory
+    s_xrow[p] = xrow; s_rt[p] = rt; s_ga[p] = (float)ga; s_env[p] = my_env; s_sum[tid] = 0.0;
   }
   __syncthreads();
   // ---- A fragment of one row tile: lane l holds x[row = l & 15][slot = 4 ks + (l >> 4)], f32 until used
@@ -119,7 +176,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
     const uint32_t xr = s_xrow[row];  // rows past the end carry xrow = 0 (a valid address) and zero run-time fields:
                                       // loaded unconditionally, their results are never stored
 #pragma unroll
-    for (int ks = 0; ks < ROWF / 4; ++ks) af[ks] = Xf[xr + 4 * ks + q];
+    for (int ks = 0; ks < KS; ++ks) af[ks] = Xf[xr + 4 * ks + q];
     const float4 rt = s_rt[row];  // k-step 6 = slots 24..27: the run-time fields replace the table's zeros
     af[RT_QUAD] = q == 0 ? rt.x : q == 1 ? rt.y : q == 2 ? rt.z : rt.w;
   };
@@ -137,9 +194,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
     const int seg_end = lo;
     for (int n0 = 0; n0 < n_samples; n0 += PM_NPAD) {
       __syncthreads();  // previous users of sB are done
-      // stage B_col: W[(col * n_samples + s)][head][slot] -> sB[head][slot][s - n0]; 16-B global loads
+      // stage B_col: W[(col * n_samples + s)][head][slot] -> sB[head][slot][s - n0]; 16-B global loads, consecutive
+      // lanes take consecutive draws so the four LDS stores of a lane group fall into distinct banks
       for (int idx = tid; idx < PM_NPAD * 2 * (ROWF / 4); idx += BLOCK) {
-        const int s = idx >> 4, rem = idx & 15;
+        const int s = idx % PM_NPAD, rem = idx / PM_NPAD;
         const int head = rem >> 3, k4 = rem & 7;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n0 + s < n_samples)
@@ -148,14 +206,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
       }
       __syncthreads();
       const int tiles = (min(PM_NPAD, n_samples - n0) + 15) >> 4;
-      float afn[ROWF / 4];  // the next row tile's A fragment is requested while the current one computes
+      float afn[KS];  // the next row tile's A fragment is requested while the current one computes
       load_a(wave * PM_TILES_PER_WAVE, afn);
 #pragma unroll 1
       for (int i = 0; i < PM_TILES_PER_WAVE; ++i) {
         const int w_lo = (wave * PM_TILES_PER_WAVE + i) * 16, w_hi = w_lo + 16;
-        double ad[ROWF / 4];
+        double ad[KS];
 #pragma unroll
-        for (int ks = 0; ks < ROWF / 4; ++ks) ad[ks] = (double)afn[ks];
+        for (int ks = 0; ks < KS; ++ks) ad[ks] = (double)afn[ks];
         if (i + 1 < PM_TILES_PER_WAVE) load_a(wave * PM_TILES_PER_WAVE + i + 1, afn);
         if (!(seg < w_hi && seg_end > w_lo)) continue;  // no row of this tile in the segment (wave-uniform)
         float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // per accumulator row (q + 4 j): sum over this lane's <= 7 draws (each
@@ -166,56 +224,53 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
         // effectiveness enters only through eff * gate * actual: when no row of this tile has an open gate AND an
         // alert today (most tiles: alerts are budget-limited), its half of the GEMM and its sigmoids are skipped
         const bool any_eff = __any(ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f || ga[3] != 0.0f);
-        // one 16-draw tile: 8 (+ 8) MFMAs and the epilogue. The effectiveness fragment is read from LDS before the
-        // baseline MFMAs are issued, the NEXT tile's baseline fragment (into `nb`) before the effectiveness ones:
-        // LDS latency sits under 512 cycles of MFMA. Two named buffers alternate (the loop is unrolled by two), so
-        // no fragment is ever copied between registers.
-        auto do_tile = [&](int nt, const PmB &cb, PmB &nb) {
+        // one 16-draw tile: KS (+ KS) MFMAs and the epilogue, compiled twice (with / without the effectiveness head:
+        // a wave-uniform choice per row tile). The effectiveness fragment is read from LDS before the baseline MFMAs
+        // are issued, the NEXT tile's baseline fragment (into `nb`) before the effectiveness ones: LDS latency sits
+        // under the MFMAs. Two named buffers alternate (the loop is unrolled by two).
+        auto do_tile = [&](auto eff_c, int nt, const PmB<KS> &cb, PmB<KS> &nb) {
+          constexpr bool EFF = decltype(eff_c)::value;
           const int nn = nt * 16 + (lane & 15);
-          PmB ce;
-          if (any_eff) ce = pm_load_b(sB[1], q, nn);
-          else if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
-          pm_double4 accb = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
-#if W2A_PM_EXPERIMENT == 2  // timing experiment: VALU FMA instead of MFMA (results wrong)
+          PmB<KS> ce;
+          if (EFF) ce = pm_load_b<KS>(sB[1], q, nn);
+          else if (nt + 1 < tiles) nb = pm_load_b<KS>(sB[0], q, nn + 16);
+          const double zb0 = KS == ROWF / 4 ? 0.0 : (double)cb.bias;
+          pm_double4 accb = {zb0, zb0, zb0, zb0};
+          if (EFF) {  // two independent accumulation chains, interleaved
+            const double ze0 = KS == ROWF / 4 ? 0.0 : (double)ce.bias;
+            pm_double4 acce = {ze0, ze0, ze0, ze0};
+            if (nt + 1 < tiles) nb = pm_load_b<KS>(sB[0], q, nn + 16);
 #pragma unroll
-          for (int ks = 0; ks < ROWF / 4; ++ks) accb[ks & 3] = fma(ad[ks], (double)cb.v[ks], accb[ks & 3]);
-          if (any_eff) {
-            if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
-#pragma unroll
-            for (int ks = 0; ks < ROWF / 4; ++ks) acce[ks & 3] = fma(ad[ks], (double)ce.v[ks], acce[ks & 3]);
-          }
-#else
-          if (any_eff) {  // wave-uniform: two independent accumulation chains, interleaved
-            if (nt + 1 < tiles) nb = pm_load_b(sB[0], q, nn + 16);
-#pragma unroll
-            for (int ks = 0; ks < ROWF / 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
               accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
               acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)ce.v[ks], acce, 0, 0, 0);
             }
+            if (n0 + nn < n_samples) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)  // D[row = q + 4 j][col = lane & 15]
+                rs[j] += sigmoid_f32((float)accb[j]) * (1.0f - sigmoid_f32((float)acce[j]) * ga[j]);
+            }
           } else {
 #pragma unroll
-            for (int ks = 0; ks < ROWF / 4; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
               accb = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], (double)cb.v[ks], accb, 0, 0, 0);
-          }
-#endif
-          if (n0 + nn < n_samples) {
+            if (n0 + nn < n_samples) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {  // D[row = q + 4 j][col = lane & 15]
-#if W2A_PM_EXPERIMENT == 1  // timing experiment: no sigmoid epilogue (results wrong)
-              rs[j] += (float)accb[j] + (float)acce[j];
-#else
-              const float base = sigmoid_f32((float)accb[j]);
-              float keep = 1.0f;
-              if (any_eff) keep = 1.0f - sigmoid_f32((float)acce[j]) * ga[j];
-              rs[j] += base * keep;
-#endif
+              for (int j = 0; j < 4; ++j) rs[j] += sigmoid_f32((float)accb[j]);
             }
           }
         };
-        PmB b0 = pm_load_b(sB[0], q, lane & 15), b1;
-        for (int nt = 0; nt < tiles; nt += 2) {
-          do_tile(nt, b0, b1);
-          if (nt + 1 < tiles) do_tile(nt + 1, b1, b0);
+        PmB<KS> b0 = pm_load_b<KS>(sB[0], q, lane & 15), b1;
+        if (any_eff) {
+          for (int nt = 0; nt < tiles; nt += 2) {
+            do_tile(std::true_type{}, nt, b0, b1);
+            if (nt + 1 < tiles) do_tile(std::true_type{}, nt + 1, b1, b0);
+          }
+        } else {
+          for (int nt = 0; nt < tiles; nt += 2) {
+            do_tile(std::false_type{}, nt, b0, b1);
+            if (nt + 1 < tiles) do_tile(std::false_type{}, nt + 1, b1, b0);
+          }
         }
         // sum over the 16 lanes that share q (one DPP row): xor 1, xor 2, half mirror, mirror
 #pragma unroll
@@ -234,7 +289,325 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
   }
   __syncthreads();
   if (s_col[tid] != 0xFFFFFFFFu)
-    a.reward[my_env] = (float)(-(1000.0 / 152.0) * s_sum[tid] / (double)n_samples);
+    a.reward[s_env[tid]] = (float)(-(1000.0 / 152.0) * s_sum[tid] / (double)n_samples);
+}
+
+// ----------------------------------------------------------------------------------------
+// lane = env form (default): fp64 FMAs on the vector ALU, coefficients broadcast by DPP
+// ----------------------------------------------------------------------------------------
+// On MI355X the fp64 matrix rate equals the fp64 vector rate (v_mfma_f64_16x16x4 = 64 cycles for 1024 FMAs,
+// v_fma_f64 = 4 cycles for 64) and fp64 MFMAs do not overlap ANY other vector work (tools/mfma_overlap_probe.hip:
+// MFMAs and f32 sigmoids interleaved in one wave take the sum of their times): the matrix form buys no arithmetic and
+// pays for its fragments (B through LDS with a convert per use, 112-for-100 draw padding, a cross-lane reduction).
+// What the matrix unit does provide is operand delivery, and the vector unit has a second way to get it: gfx90a+
+// DPP on 64-bit operations, row_newbcast:n = lane n of every 16-lane row broadcast to the row. So:
+//   * a wave serves 64 envs of one coefficient column, lane = env; the env's feature row of the day (run-time slots
+//     patched in) sits in registers as 28 (32) doubles;
+//   * the workgroup stages the column's block of a fp64 copy of W that already carries the factor -log2(e) (k_pm_wd,
+//     once per episode) in LDS; per draw every lane reads TWO doubles of the draw's coefficient row, slots (lane & 15)
+//     and 16 + (lane & 15): 8 LDS cycles per wave and draw;
+//   * v_fmac_f64_dpp acc, coef row_newbcast:k, x[k] -- 28 FMAs over two chains, one of them started from the
+//     broadcast bias -- then v_exp_f32 + v_rcp_f32 and one fp64 add: exactly n_samples draws, the sum over draws
+//     lane-local. 37 vector instructions per env-wave and draw.
+// The effectiveness head matters for the few rows with gate * actual = 1 only. The rows of a workgroup are re-ordered
+// so that these sit first in their column segment; after the baseline pass EVERY wave of the workgroup takes the
+// same group of <= 64 such rows and an eighth of the draws with both heads, and the row's owner adds the eight
+// partial sums in a fixed order: the extra work is spread evenly instead of making one wave a straggler.
+// Every lane of a wave stays active in the draw loops (DPP reads its source lane whatever that lane's own row is).
+#ifndef PMV_THREADS
+#define PMV_THREADS 512
+#endif
+#ifndef W2A_PMV_CHAINS
+#define W2A_PMV_CHAINS 1           // accumulation chains per logit (A/B: 2 = two interleaved chains, 2 more instructions)
+#endif
+#ifndef W2A_PMV_NPAD
+#define W2A_PMV_NPAD 112           // draws staged in LDS per pass
+#endif
+__global__ void k_pm_wd(const float *W, double *wd, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) wd[i] = -1.4426950408889634 * (double)W[i];
+}
+
+// z0, z1 += sum_k coef[k] * x[k] for slots held by `b` (lane n of each 16-lane row holds slot base + n). The leading
+// s_nop covers the VALU-write -> DPP-read hazard should the compiler have just moved `b` between registers.
+__device__ __forceinline__ void pmv_fma16(double &z0, double &z1, double b, const double *x) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(z0), "+v"(z1)
+      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+        "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
+}
+__device__ __forceinline__ void pmv_fma12(double &z0, double &z1, double b, const double *x) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(z0), "+v"(z1)
+      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+        "v"(x[9]), "v"(x[10]), "v"(x[11]));
+}
+// single-chain forms (W2A_PMV_CHAINS == 1): two instructions fewer per draw; the dependent FMAs of one wave are
+// interleaved with those of the SIMD's other waves
+__device__ __forceinline__ void pmv_fma16(double &z0, double b, const double *x) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(z0)
+      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+        "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
+}
+__device__ __forceinline__ void pmv_fma12(double &z0, double b, const double *x) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(z0)
+      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+        "v"(x[9]), "v"(x[10]), "v"(x[11]));
+}
+// lane 13 of every row holds slot 29, the bias
+__device__ __forceinline__ double pmv_bias(double b) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:13 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(b));
+  return r;
+}
+// one head's logit (times -log2 e) of the lane's env for the draw whose coefficient row is sWd = [slot]
+template <int KS>
+__device__ __forceinline__ float pmv_logit(const double *sWd, int l15, const double (&ax)[4 * KS]) {
+  const double b0 = sWd[l15], b1 = sWd[16 + l15];
+#if W2A_PMV_CHAINS == 1
+  double z = KS == ROWF / 4 ? 0.0 : pmv_bias(b1);
+  pmv_fma16(z, b0, &ax[0]);
+  if (KS == ROWF / 4) pmv_fma16(z, b1, &ax[16]);
+  else pmv_fma12(z, b1, &ax[16]);
+  return (float)z;
+#else
+  double z0, z1 = 0.0;
+  if (KS == ROWF / 4) {  // all 32 slots (slot 29 of the row holds 1.0)
+    z0 = 0.0;
+    pmv_fma16(z0, z1, b0, &ax[0]);
+    pmv_fma16(z0, z1, b1, &ax[16]);
+  } else {               // slots 0..27, chain 0 starts from the bias
+    z0 = pmv_bias(b1);
+    pmv_fma16(z0, z1, b0, &ax[0]);
+    pmv_fma12(z0, z1, b1, &ax[16]);
+  }
+  return (float)(z0 + z1);
+#endif
+}
+
+// sigmoid(zb) [* (1 - sigmoid(ze))] of the lane's env for staged draw s; sW = [draw][head][slot]
+template <int KS, bool EFF>
+__device__ __forceinline__ float pmv_term(const double (*sW)[2][ROWF], int s, int l15, const double (&ax)[4 * KS]) {
+  float t = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pmv_logit<KS>(sW[s][0], l15, ax)));
+  if (EFF) t *= 1.0f - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pmv_logit<KS>(sW[s][1], l15, ax)));
+  return t;
+}
+
+// baseline pass: sum over `draws` staged draws of sigmoid(zb). Four terms (each in [0, 1]) are added in f32 (error
+// <= 3 ulp(4) = 7e-7 per block), the blocks in fp64.
+template <int KS>
+__device__ __forceinline__ double pmv_draws(const double (*sW)[2][ROWF], int draws, int l15, const double (&ax)[4 * KS]) {
+  double sum = 0.0;
+#ifdef W2A_PMV_DEBUG_DRAWS  // timing experiment: cap the draw loop (results wrong)
+  draws = min(draws, W2A_PMV_DEBUG_DRAWS);
+#endif
+  int s = 0;
+#pragma unroll 1
+  for (; s + 4 <= draws; s += 4)
+    sum += (double)((pmv_term<KS, false>(sW, s, l15, ax) + pmv_term<KS, false>(sW, s + 1, l15, ax)) +
+                    (pmv_term<KS, false>(sW, s + 2, l15, ax) + pmv_term<KS, false>(sW, s + 3, l15, ax)));
+#pragma unroll 1
+  for (; s < draws; ++s) sum += (double)pmv_term<KS, false>(sW, s, l15, ax);
+  return sum;
+}
+
+// f32 row (as loaded / staged) -> the doubles of the FMA blocks. The empty asm makes the f32 values opaque at this
+// point, so the 28 converts stay where they are written instead of being hoisted out of the segment loop (which
+// would keep the f32 AND the fp64 row live for the whole kernel and halve the occupancy).
+template <int KS>
+__device__ __forceinline__ void pmv_widen(float4 (&xf)[KS], double (&ax)[4 * KS]) {
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    asm volatile("" : "+v"(xf[q].x), "+v"(xf[q].y), "+v"(xf[q].z), "+v"(xf[q].w));
+    ax[4 * q] = xf[q].x; ax[4 * q + 1] = xf[q].y; ax[4 * q + 2] = xf[q].z; ax[4 * q + 3] = xf[q].w;
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(PMV_THREADS) void k_posterior_mean_v(const PosteriorArgs a) {
+  constexpr int ROWS = PMV_THREADS;  // sorted positions per workgroup, lane = row
+  constexpr int WAVES = PMV_THREADS / 64;
+  __shared__ uint32_t s_col[ROWS];
+  __shared__ uint32_t s_G[ROWS + 1];                // rows with gate * actual = 1 before row r
+  __shared__ uint32_t s_wga[WAVES];
+  __shared__ double sW[W2A_PMV_NPAD][2][ROWF];      // the segment's coefficient block
+  __shared__ float4 s_ax[64][KS];                   // effectiveness phase: the rows of one group, as f32
+  __shared__ double s_part[WAVES][64];              // effectiveness phase: per-wave, per-lane partial sums
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  // XCD k walks the k-th contiguous eighth of the sorted positions: the 2-3 workgroups of a coefficient column run
+  // on one XCD and its block comes out of that XCD's L2 after the first of them has staged it
+  const int64_t pos0 = (int64_t)logical_block(blockIdx.x, gridDim.x >> 3) * ROWS;
+  if (pos0 >= a.n) return;  // the grid is rounded up to a multiple of 8
+  // ---- set-up: the row's record (coalesced), its feature row of the day (requested at once, kept as f32 for the
+  // whole kernel), and the count of effectiveness rows before it
+  uint4 rec = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);  // past the end: feature row 0 (a valid address), never stored
+  if (pos0 + tid < a.n) rec = a.prep[pos0 + tid];   // x feature row, y run-time fields, z column, w env id
+  float4 xf[KS];
+  {
+    const float4 *xp = a.tb.X + (rec.x >> 2);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) xf[q] = xp[q];
+    xf[RT_QUAD] = make_float4((float)(rec.y & 1u), (float)((rec.y >> 1) & 1023u), (float)(rec.y >> 16),
+                              (float)((rec.y >> 11) & 15u));  // slots 24..27: the run-time fields of k_pm_prep
+  }
+  const uint32_t ga = (rec.y >> 15) & 1u;
+  uint32_t G;
+  {
+    const uint64_t bal = __ballot(ga != 0);
+    G = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    s_col[tid] = rec.z;
+    if (lane == 0) s_wga[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) G += s_wga[w];
+    s_G[tid] = G;
+    if (tid == ROWS - 1) s_G[ROWS] = G + ga;
+    __syncthreads();
+  }
+  const int n_samples = a.tb.n_samples;
+  double sum = 0.0;
+  // ---- column segments of the workgroup's rows (sorted by column: a segment is a contiguous run; one, sometimes
+  // two, at bench sizes). The segment's coefficient block is staged in LDS once per pass of <= W2A_PMV_NPAD draws.
+  int seg = 0;
+  while (seg < ROWS) {
+    // (LDS reads of wave-uniform addresses: readfirstlane tells the compiler the values are scalar)
+    const uint32_t col = __builtin_amdgcn_readfirstlane(s_col[seg]);
+    if (col == 0xFFFFFFFFu) break;
+    int lo = seg + 1, hi = ROWS;      // seg_end = first row whose column is larger (binary search)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__builtin_amdgcn_readfirstlane(s_col[mid]) > col) hi = mid; else lo = mid + 1;
+    }
+    const int seg_end = lo;
+    const uint32_t g_seg = __builtin_amdgcn_readfirstlane(s_G[seg]);
+    const int n_eff = (int)(__builtin_amdgcn_readfirstlane(s_G[seg_end]) - g_seg);  // rows that need the effectiveness head
+    const bool in_seg = tid >= seg && tid < seg_end;
+    const bool wave_in = seg < 64 * (wave + 1) && seg_end > 64 * wave;  // wave-uniform
+    for (int n0 = 0; n0 < n_samples; n0 += W2A_PMV_NPAD) {
+      const int draws = min(W2A_PMV_NPAD, n_samples - n0);
+      __syncthreads();  // previous users of sW are done
+      // stage wd[(col * n_samples + n0 + s)][head][slot] -> sW[s][head][slot]: 16-B loads and stores, coalesced
+      {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.wd + ((size_t)col * n_samples + n0) * (2 * ROWF));
+        uint4 *dst = reinterpret_cast<uint4 *>(&sW[0][0][0]);
+        for (int idx = tid; idx < draws * (2 * ROWF / 2); idx += PMV_THREADS)
+          if (n_eff || !((idx >> 4) & 1)) dst[idx] = src[idx];  // 16 uint4 per head row
+      }
+      __syncthreads();
+      double contrib = 0.0;
+      // baseline pass: the wave's own rows, every draw (rows of other segments compute a value that is dropped)
+      if (wave_in) {
+        double ax[4 * KS];
+        pmv_widen<KS>(xf, ax);
+        contrib = pmv_draws<KS>(sW, draws, l15, ax);
+      }
+      // effectiveness phase, groups of <= 64 rows: their owners publish the rows, then EVERY wave takes an eighth of
+      // the draws with both heads. A group of cnt rows fills R = ceil(cnt / 16) DPP rows of a wave; the wave's other
+      // DPP rows work on other draws of its eighth at the same time (P = 4 / R draws in flight).
+      for (int grp = 0; grp < n_eff; grp += 64) {
+        const int cnt = min(64, n_eff - grp);
+        const int j_own = (int)(G - g_seg) - grp;  // this thread's row is row j_own of the group (if it is one)
+        const bool own = in_seg && ga && j_own >= 0 && j_own < 64;
+        if (own) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) s_ax[j_own][q] = xf[q];
+        }
+        __syncthreads();
+        const int R = (cnt + 15) >> 4, P = R == 1 ? 4 : (R == 2 ? 2 : 1);
+        const int drow = lane >> 4;                // DPP row of the lane
+        const int j = l15 + 16 * (drow % R);       // group row served by the lane
+        const int sub = drow / R;                  // which of the P draws in flight
+        const int d0 = wave * draws / WAVES, d1 = (wave + 1) * draws / WAVES;
+        double part = 0.0;
+        {
+          float4 ef[KS];
+#pragma unroll
+          for (int q = 0; q < KS; ++q) ef[q] = s_ax[j < cnt ? j : 0][q];
+          double ax[4 * KS];
+          pmv_widen<KS>(ef, ax);
+#pragma unroll 1
+          for (int s = d0; s < d1; s += P) {       // uniform trip count; lanes past the slice redo its last draw
+            const int sl = s + sub;
+            const float t = pmv_term<KS, true>(sW, sl < d1 ? sl : d1 - 1, l15, ax);
+            part += (sl < d1 && sub < P) ? (double)t : 0.0;
+          }
+        }
+        s_part[wave][lane] = part;
+        __syncthreads();
+        if (own) {
+          double t = 0.0;
+#pragma unroll 1
+          for (int w = 0; w < WAVES; ++w)
+#pragma unroll 1
+            for (int p = 0; p < P; ++p) t += s_part[w][(j_own & 15) + 16 * ((j_own >> 4) + R * p)];
+          contrib = t;  // replaces the baseline-only value
+        }
+      }
+      sum += in_seg ? contrib : 0.0;
+    }
+    seg = seg_end;
+  }
+  if (rec.z != 0xFFFFFFFFu) a.reward[rec.w] = (float)(-(1000.0 / 152.0) * sum / (double)n_samples);
 }
 
 #endif  // W2A_POSTERIOR_HIP_H
