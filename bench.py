@@ -521,23 +521,24 @@ def main():
                 "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
                         "row after each reset"}
             e3.close()
-            # (3) reward_mode="posterior_mean": the reward of every env-step as the mean over all 100 posterior draws,
-            # a grouped fp64-MFMA GEMM per step (the dense "nn_full_medicare reward GEMM" of BASELINE configs[3]/[4])
+            # (3) reward_mode="posterior_mean": the reward of every env-step as the mean over all 100 posterior draws
+            # (the dense "nn_full_medicare reward GEMM" of BASELINE configs[3]/[4]): fp64 FMAs on the vector ALU with
+            # DPP-broadcast coefficients (the fp64 MFMA form is an A/B build)
             e4 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
                                  write_obs=not args.no_obs, reward_mode="posterior_mean")
             e4.reset(seed=args.seed)
             timed_steps(e4, pool, 5, torch)
             kms, _ = timed_steps(e4, pool, 40, torch)
             us = kms * 1e3 / 40
-            flop_algo = 2.0 * 28 * 2 * ct.n_samples * n          # 28 coefficients x 2 heads x draws, multiply-add
-            flop_mfma = 2.0 * 32 * 2 * 112 * n                   # issued: K padded to 32 slots, draws to 7 x 16
+            flop_base = 2.0 * 28 * ct.n_samples * n              # baseline head: 28 coefficients x draws, multiply-add
             out["posterior_mean_reward"] = {
-                "us_per_step": us, "value": n / us * 1e6, "unit": "env-steps/s (k_posterior_mean + k_step64<given>)",
-                "gemm_tflops_algorithmic": flop_algo / (us * 1e-6) / 1e12,
-                "gemm_tflops_issued": flop_mfma / (us * 1e-6) / 1e12,
-                "mfma_peak_tflops_fp64": 78.6,
-                "note": "per step: [envs of a column x 32 slots] x [32 x 2 heads x 100 draws] on v_mfma_f64_16x16x4_f64, "
-                        "f32 sigmoid / gate / mean epilogue; time includes the step kernel that consumes the reward"}
+                "us_per_step": us, "value": n / us * 1e6,
+                "unit": "env-steps/s (k_pm_prep + k_posterior_mean_v + k_step64<given>)",
+                "tflops_fp64_baseline_head": flop_base / (us * 1e-6) / 1e12,
+                "vector_peak_tflops_fp64": 78.6,
+                "note": "per step: [envs of a column x 28 slots + bias] x [draws], lane = env, v_fmac_f64_dpp row_newbcast, "
+                        "f32 sigmoid / gate / mean; the effectiveness head only for rows with an open-gate alert; time "
+                        "includes the pre-pass and the step kernel that consumes the reward"}
             e4.close()
             # (4) the single-GPU rate of the multi-GPU default workload (configs[4] = nn_full_medicare_all shape), so
             # that `--gpus N` values have their own N = 1 denominator in this file

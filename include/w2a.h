@@ -172,11 +172,13 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
 /* reward_mode = "posterior_mean" (the legacy env's eval mode, _deprecated/env.py:332-342: `posterior_indices =
  * np.arange(n_posterior_samples) if eval_mode`, `np.mean([_get_reward(i, ...)])`, on today's reward form
  * env.py:197-226): the reward of every env is the mean over ALL posterior draws of its coefficient column
- * instead of the one draw of the episode. One grouped fp64-MFMA GEMM per step: per column
+ * instead of the one draw of the episode. One grouped fp64 contraction per step: per column
  * [envs x 32 slots] * [32 slots x 2 heads x n_samples draws], sigmoid / gate / mean epilogue.
  *   w2a_group_by_column        after EVERY reset: sorts the env ids by coefficient column into `workspace`
- *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples), 256-B aligned, must stay alive
- *                              while w2a_posterior_mean_reward is used);
+ *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples), 256-B aligned, must
+ *                              stay alive while w2a_posterior_mean_reward is used) and writes a pre-scaled fp64 copy
+ *                              of W there. W rows that give slot 28, 30 or 31 a coefficient are honoured (w2a_create
+ *                              scans for them once) at the price of a wider contraction;
  *   w2a_posterior_mean_reward  before w2a_step(..., W2A_STEP_REWARD_GIVEN) with the SAME actions: writes
  *                              reward [num_envs] f32 from the pre-step state. Same budget gate as the step
  *                              (env.py:242-246): an alert attempted at budget counts as no alert. */

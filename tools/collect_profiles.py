@@ -18,7 +18,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO = os.path.join(ROOT, "gpurun_out")
 GIB = float(1 << 30)
-KEEP = ("k_step", "k_reset", "k_posterior", "k_rollout", "k_group", "copyBuffer", "FillFunctor")
+KEEP = ("k_step", "k_reset", "k_posterior", "k_pm_", "k_rollout", "k_group", "copyBuffer", "FillFunctor")
 
 
 def newest(pattern):
@@ -102,7 +102,8 @@ def main():
     for tag in a.tags:
         collect(tag, out, a.round)
     logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
-            "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log"]
+            "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log", "pm_trace.log",
+            "pm_variants.log", "pm_tests_matrix.log", "mfma_overlap_probe.log"]
     for f in logs:
         src = os.path.join(GO, f)
         if os.path.exists(src):

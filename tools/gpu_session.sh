@@ -56,9 +56,9 @@ for step in "$@"; do
       tag=$w; extra=""; bextra=""
       if [ "$order" == "sorted" ]; then tag=${w}_sorted; extra="--episode-order sorted"; bextra="--episode-order sorted"; fi
       if [ "$order" == "pm" ]; then
-        # posterior-mean GEMM: MFMA counters only (the kernel trace of bench.py already lists k_posterior_mean)
+        # posterior-mean reward kernel: issue counters (the kernel trace of bench.py already lists k_posterior_mean_v)
         tag=${w}_pm
-        for grp in "mfma:SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+        for grp in "mfma:SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
           name=${grp%%:*}; ctrs=${grp#*:}
           timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $PWD/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w --reward-mode posterior_mean --steps 12 > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
           python tools/rocprof_summary.py gpurun_out/prof_${name}_$tag --json gpurun_out/prof_${name}_$tag.summary.json > gpurun_out/prof_${name}_$tag.summary.txt 2>&1

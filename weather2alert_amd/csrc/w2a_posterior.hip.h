@@ -1,6 +1,8 @@
-// w2a_posterior.hip.h -- k_posterior_mean: today's reward averaged over ALL posterior draws of the env's
-// coefficient column (the legacy env's eval mode, _deprecated/env.py:332-342, on today's linear-logistic form
-// env.py:197-226), as a grouped fp64-MFMA GEMM per coefficient column; k_group_keys feeds the grouping sort.
+// w2a_posterior.hip.h -- today's reward averaged over ALL posterior draws of the env's coefficient column (the
+// legacy env's eval mode, _deprecated/env.py:332-342, on today's linear-logistic form env.py:197-226): the pre-pass
+// k_pm_prep, the default kernel k_posterior_mean_v (fp64 vector FMAs, DPP-broadcast coefficients; second half of
+// this file) and the fp64-MFMA form k_posterior_mean (A/B build -DW2A_PM_MATRIX=1); k_group_keys / k_group_inverse /
+// k_pm_wd feed the once-per-episode grouping.
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
 #ifndef W2A_POSTERIOR_HIP_H
 #define W2A_POSTERIOR_HIP_H
@@ -11,7 +13,8 @@
 //     zb_s = sum_k x_k * Wb[c][s][k],   ze_s = sum_k x_k * We[c][s][k]          (k over the 32 row slots)
 // i.e. per column c one dense contraction  D_c [N_c envs][2 * n_samples] = A_c [N_c][32] * B_c [32][2 * n_samples]
 // followed by a sigmoid / product / mean epilogue. Envs are served in the order of `perm` (env ids sorted by
-// column, built once per episode by w2a_group_by_column), so a 256-row tile spans one column, sometimes two:
+// column, built once per episode by w2a_group_by_column). The MATRIX form (k_posterior_mean): a 256-row tile spans one
+// column, sometimes two:
 //   * the workgroup stages B_c (both heads, all draws: 25.6 KB of f32) in LDS once per column segment;
 //   * each of its 4 waves owns 4 row tiles of 16: A fragments = the env's feature row of the day with the run-time slots
 //     patched in (the same derive_day()/runtime_fields() as the step kernel), converted f32 -> f64 in registers;
