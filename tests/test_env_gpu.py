@@ -862,13 +862,16 @@ def test_other_schema_parity(dev):
 
 @pytest.mark.parametrize("n,n_fips,n_samples,augment,adversarial,tail", [
     (3000 + 5, 48, 12, True, False, False), (37, 30, 100, False, False, False), (4096, 746, 100, True, False, False),
-    (2048 + 9, 40, 20, True, True, False), (1500 + 3, 48, 12, True, False, True)])
+    (2048 + 9, 40, 20, True, True, False), (1500 + 3, 48, 12, True, False, True),
+    (1500 + 7, 3, 130, False, False, False)])
 def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial, tail):
     """reward_mode='posterior_mean' (legacy eval mode, _deprecated/env.py:332-342, on today's reward form): the
     grouped fp64-MFMA GEMM + sigmoid/mean epilogue against the oracle's mean over every posterior draw; everything
     but the reward (observations, integer state, termination) equals the sampled-reward env. Ragged draw counts
     (12: a partial 16-column MFMA tile), tiles that span many coefficient columns (n = 37), the full 746-column
-    table, and augmentation (Q8: the coefficient column differs from the weather county). 'tail' gives slot 31 (always
+    table, augmentation (Q8: the coefficient column differs from the weather county), and 3 columns x 130 draws: column
+    segments longer than a workgroup with more than 64 effectiveness rows each (several row groups in the
+    effectiveness phase) and more draws than one LDS staging pass holds. 'tail' gives slot 31 (always
     zero in the feature rows) a coefficient: w2a_create then selects the kernel that contracts all 32 slots instead of
     slots 0..27 + bias, and the reward must not change."""
     from weather2alert_amd import HeatAlertVecEnv
