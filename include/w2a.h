@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 5
+#define W2A_ABI_VERSION 6
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -232,6 +232,15 @@ typedef struct w2a_policy {
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
                 int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
                 float *last_return, float *ret_snapshot, void *stream);
+
+/* One day of a built-in policy: actions i32 [n] of every env from its pre-step state -- the same policy evaluation,
+ * lagging observation and budget gate as w2a_rollout (finished envs get action 0) -- for policy loops whose step is
+ * w2a_step, e.g. with w2a_posterior_mean_reward. Nullable accumulators, updated for today: alerts i32 [n] += alert
+ * issued, attempts_over_budget i32 [n] += alert attempted at budget, alert_mask / attempt_mask u32 [n][mask_words]
+ * |= bit (day) -- the caller zeroes them before the first day. */
+int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions, int32_t *alerts,
+                       int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
+                       void *stream);
 
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);

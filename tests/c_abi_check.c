@@ -21,6 +21,7 @@ int main(void) {
   if (!strstr(w2a_last_error(), "NULL")) return 5;
   if (w2a_step(NULL, NULL, W2A_ACT_I32, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 6;
   if (w2a_rollout(NULL, &p, 1, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL) != W2A_ERR_ARG) return 7;
+  if (w2a_policy_actions(NULL, &p, NULL, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 10;
   if (w2a_set_semantics(NULL, W2A_FIX_ALL) != W2A_ERR_ARG) return 8;
   if (w2a_sort_workspace_bytes(0) != 0) return 9;
   printf("w2a C ABI v%d ok, sizeof(w2a_tables)=%zu\n", w2a_abi_version(), sizeof(w2a_tables));

@@ -913,11 +913,64 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
         assert torch.equal(s1[k], s2[k]), k
     np.testing.assert_allclose(s1["episode_return"].cpu().numpy(), ret, rtol=2e-5, atol=1e-4)
     assert pm.check_status() == 0
-    with pytest.raises(ValueError):
-        pm.rollout(dict(kind="never"))
     print(f"posterior mean n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
     pm.close()
     sm.close()
+
+
+@pytest.mark.parametrize("kind", ["bernoulli", "threshold", "table"])
+def test_posterior_mean_rollout_matches_policy_loop(dev, kind):
+    """rollout() with reward_mode='posterior_mean' (policy kernel + reward kernels + step kernel per day) against the
+    oracle's policy loop on the all-draws reward: alerts, over-budget attempts and alert days exact, returns to f32
+    accumulation accuracy; a partial rollout, explicit steps in between, then the rest; and the next episode after the
+    lock-step autoreset."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=30, years=[2006, 2007], n_samples=6, seed=17, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    n, gid0 = 700, 1000
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, env_gid0=gid0, similar_climate_counties=True,
+                          reward_mode="posterior_mean")
+    env.reset(seed=21, options={"budget": 7})
+    st = _oracle_for_env(env, V)
+    rng = np.random.default_rng(0)
+    table = (rng.random((ct.T, 5)) < 0.3).astype(np.uint8)
+    pol = {"bernoulli": dict(kind="bernoulli", p=0.15, seed=99),
+           "threshold": dict(kind="threshold", feature="heat_qi", threshold=0.8, require_budget=True),
+           "table": dict(kind="table", table=table)}[kind]
+    opol = dict(pol, col=ct.columns.index("heat_qi"))
+    draw = (lambda i, t: O.devrng_policy_uniform(99, gid0 + i, int(st["episode_no"][i]), t)) if kind == "bernoulli" else None
+
+    def check(out, n_steps):
+        ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, opol, n_steps, draw)
+        np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
+        np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
+        np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
+        np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+        return ret_o
+
+    r1 = check(env.rollout(pol, n_steps=40, alert_mask=True), 40)
+    r2 = np.zeros(n)
+    for _ in range(5):
+        a = (rng.random(n) < 0.2).astype(np.int32)
+        _, r, _, _, _ = env.step(torch.as_tensor(a, device=dev))
+        _, r_o, _, _ = V.step(a)
+        assert np.abs(r.cpu().numpy() - r_o).max() <= REWARD_TOL
+        r2 += r_o
+    out = env.rollout(pol, alert_mask=True)
+    r3 = check(out, ct.T)
+    assert out["done"].all() and (out["first_day"] == 45).all()
+    np.testing.assert_allclose(out["final_return"].cpu().numpy(), r1 + r2 + r3, rtol=2e-5, atol=1e-3)
+    # the batch was reset after its terminal day (lock step, same_step): the next call evaluates the next episode
+    assert (env.state()["episode_no"] == 1).all() and (env.state()["t"] == 0).all()
+    st = _oracle_for_env(env, V)
+    out = env.rollout(pol, alert_mask=True)
+    check(out, ct.T)
+    stats = HeatAlertVecEnv.episode_stats(out)
+    assert out["done"].all() and "average_t_alerts" in stats
+    assert env.check_status() == 0
+    env.close()
 
 
 def test_posterior_mean_with_a_coefficient_on_the_25th_table_column(dev):

@@ -425,6 +425,32 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   return W2A_OK;
 }
 
+int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions, int32_t *alerts,
+                       int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
+                       void *stream) {
+  if (!env || !policy || !actions) return fail(W2A_ERR_ARG, "w2a_policy_actions: NULL argument");
+  if (policy->kind < W2A_POLICY_NEVER || policy->kind > W2A_POLICY_TABLE) return fail(W2A_ERR_ARG, "w2a_policy_actions: bad policy kind");
+  if (policy->kind == W2A_POLICY_TABLE && (!policy->table || policy->table_R <= 0))
+    return fail(W2A_ERR_ARG, "w2a_policy_actions: tabular policy needs table [T][table_R] and table_R > 0");
+  if ((alert_mask || attempt_mask) && mask_words * 32 < env->tb.T)
+    return fail(W2A_ERR_ARG, "w2a_policy_actions: alert_mask / attempt_mask need ceil(T/32) words per env");
+  PolicyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tb = env->tb; a.st = env->st; a.n = env->n; a.gid0 = env->gid0;
+  a.pol = *policy;
+  if (policy->kind == W2A_POLICY_THRESHOLD) {
+    if (policy->obs_col < 0 || policy->obs_col >= env->tb.n_obs) return fail(W2A_ERR_ARG, "w2a_policy_actions: obs_col outside the observation");
+    int slot = env->obs_slot_host[policy->obs_col];
+    if (slot >= 24 && slot <= 27) return fail(W2A_ERR_ARG, "w2a_policy_actions: threshold policies read table-sourced columns only");
+    a.pol_slot = slot;
+  }
+  a.actions = actions; a.alerts = alerts; a.attempts_over_budget = attempts_over_budget;
+  a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words;
+  hipLaunchKernelGGL(k_policy_actions, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
   if (!env || !view) return fail(W2A_ERR_ARG, "w2a_get_state: NULL argument");
   int64_t blocks = (env->n + 255) / 256;

@@ -30,6 +30,23 @@ struct RolloutArgs {
                                   // what the reference's logging callbacks read (callbacks.py:47-48,128-132)
 };
 
+// the built-in policies on what the reference's agent would see (shared by k_rollout and k_policy_actions)
+__device__ __forceinline__ int32_t policy_action(const w2a_policy &pol, uint64_t pstream, uint32_t t, int32_t rem_now,
+                                                 float feat) {
+  int32_t act = 0;
+  if (pol.kind == W2A_POLICY_ALWAYS) act = 1;
+  else if (pol.kind == W2A_POLICY_BERNOULLI) {
+    const uint32_t u = (uint32_t)(w2a_mix64(pstream + (uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull) >> 32);
+    act = ((float)u * 2.3283064365386963e-10f < pol.p) ? 1 : 0;
+  } else if (pol.kind == W2A_POLICY_THRESHOLD) act = (feat > pol.threshold) ? 1 : 0;
+  else if (pol.kind == W2A_POLICY_TABLE) {
+    int32_t rr = rem_now < 0 ? 0 : (rem_now >= pol.table_R ? pol.table_R - 1 : rem_now);
+    act = pol.table[(size_t)t * pol.table_R + rr] ? 1 : 0;
+  }
+  if (pol.require_budget && rem_now <= 0) act = 0;
+  return act;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,18 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   for (int s = 0; s < a.n_steps; ++s) {
     if (!__any(active)) break;
     // ---- policy
-    int32_t act = 0;
-    const int32_t rem_now = budget - (int32_t)used;
-    if (a.pol.kind == W2A_POLICY_ALWAYS) act = 1;
-    else if (a.pol.kind == W2A_POLICY_BERNOULLI) {
-      const uint32_t u = (uint32_t)(w2a_mix64(pstream + (uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull) >> 32);
-      act = ((float)u * 2.3283064365386963e-10f < a.pol.p) ? 1 : 0;
-    } else if (a.pol.kind == W2A_POLICY_THRESHOLD) act = (feat > a.pol.threshold) ? 1 : 0;
-    else if (a.pol.kind == W2A_POLICY_TABLE) {
-      int32_t rr = rem_now < 0 ? 0 : (rem_now >= a.pol.table_R ? a.pol.table_R - 1 : rem_now);
-      act = a.pol.table[(size_t)t * a.pol.table_R + rr] ? 1 : 0;
-    }
-    if (a.pol.require_budget && rem_now <= 0) act = 0;
+    const int32_t act = policy_action(a.pol, pstream, t, budget - (int32_t)used, feat);
     // ---- env.py:242-250
     const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
     const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
@@ -172,6 +178,58 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     if (a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
   }
+}
+
+// ----------------------------------------------------------------------------------------
+// one day of a built-in policy: the action of every env from its pre-step state (for policy loops whose step is
+// not k_rollout's: reward_mode = "posterior_mean")
+// ----------------------------------------------------------------------------------------
+// Same policy, same lagging observation, same budget gate (env.py:242-246) as k_rollout; one thread per env. Also keeps
+// the per-env rollout counters: alerts issued, alerts attempted at budget, the alert / attempt day bitmaps.
+struct PolicyArgs {
+  DevTables tb;
+  StateArrays st;
+  int64_t n;
+  int64_t gid0;
+  w2a_policy pol;
+  int32_t pol_slot;
+  int32_t *actions;               // [n] out
+  int32_t *alerts;                // [n] += alert issued today (nullable)
+  int32_t *attempts_over_budget;  // [n] += alert attempted at budget (nullable)
+  uint32_t *alert_mask;           // [n][mask_words] |= bit t (nullable)
+  uint32_t *attempt_mask;
+  int32_t mask_words;
+};
+
+__global__ void k_policy_actions(const PolicyArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const uint32_t e = (uint32_t)i;
+  uint4 c2, hot;
+  load_step_state(a.st, e, c2, hot);
+  const uint4 cold = load_cold(a.st, e);
+  const uint32_t t = D0_T(hot.x), used = D0_USED(hot.x);
+  const int32_t budget = (int32_t)hot.w;
+  int32_t act = 0;
+  if (!D1_FIN(hot.y)) {
+    float feat = 0.0f;
+    if (a.pol.kind == W2A_POLICY_THRESHOLD) {
+      const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+      const uint32_t tt = (a.pol.obs_lag && t > 0) ? t - 1 : t;  // the lagging observation (Q6)
+      feat = reinterpret_cast<const float *>(a.tb.X)[((size_t)tt * rows_per_day + cold.x) * ROWF + a.pol_slot];
+    }
+    const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+    act = policy_action(a.pol, pstream, t, budget - (int32_t)used, feat);
+    const bool atb = (int32_t)used == budget;
+    const bool actual = act == 1 && !atb;
+    if (a.alerts && actual) a.alerts[e] += 1;
+    if (a.attempts_over_budget && act == 1 && atb) a.attempts_over_budget[e] += 1;
+    if ((t >> 5) < (uint32_t)a.mask_words) {
+      if (a.alert_mask && actual) a.alert_mask[(size_t)e * a.mask_words + (t >> 5)] |= 1u << (t & 31);
+      if (a.attempt_mask && act == 1) a.attempt_mask[(size_t)e * a.mask_words + (t >> 5)] |= 1u << (t & 31);
+    }
+  }
+  a.actions[e] = act;
 }
 
 #endif  // W2A_ROLLOUT_HIP_H

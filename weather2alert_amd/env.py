@@ -563,7 +563,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
     # ------------------------------------------------------------------ rollout
     def rollout(self, policy: dict, n_steps: int | None = None, alert_mask: bool = False) -> dict:
         """Run a built-in policy inside the kernel for ``n_steps`` days (default: to the end of the episode)
-        without returning to Python between days (replaces loops like env.py:265-277).
+        without returning to Python between days (replaces loops like env.py:265-277). With
+        reward_mode="posterior_mean" the days are a host loop of policy kernel + reward kernels + step kernel (same
+        policies, same outputs): the legacy eval mode's evaluation sweep.
 
         policy: {"kind": "never" | "always"} |
                 {"kind": "bernoulli", "p": 0.1, "seed": 0} |
@@ -577,8 +579,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
         reset, so consecutive calls evaluate consecutive episodes."""
         if self._needs_reset:
             raise RuntimeError("call reset() before rollout()")
-        if self._pm:
-            raise ValueError("rollout() evaluates the sampled-posterior reward; reward_mode='posterior_mean' is step() only")
         ct = self.ct
         kind = policy.get("kind")
         if kind not in _ffi.POLICY_KINDS:
@@ -609,13 +609,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
         mask = torch.empty((n, words), dtype=torch.int32, device=dev) if alert_mask else None
         amask = torch.empty((n, words), dtype=torch.int32, device=dev) if alert_mask else None
         snap = torch.full((n,), float("nan"), dtype=torch.float32, device=dev) if alert_mask else None
-        st0 = self.state() if alert_mask else None
+        st0 = self.state() if (alert_mask or self._pm) else None
         with torch.cuda.device(dev):
-            _ffi.check(self._lib.w2a_rollout(self._h, C.byref(p), steps, out["return"].data_ptr(),
-                                             out["alerts"].data_ptr(), out["attempts_over_budget"].data_ptr(),
-                                             None if mask is None else mask.data_ptr(),
-                                             None if amask is None else amask.data_ptr(), words, self._fr_ptr,
-                                             None if snap is None else snap.data_ptr(), self._stream()), "w2a_rollout")
+            if self._pm:
+                steps = self._rollout_posterior_mean(p, steps, out, mask, amask, words, snap, st0)
+            else:
+                _ffi.check(self._lib.w2a_rollout(self._h, C.byref(p), steps, out["return"].data_ptr(),
+                                                 out["alerts"].data_ptr(), out["attempts_over_budget"].data_ptr(),
+                                                 None if mask is None else mask.data_ptr(),
+                                                 None if amask is None else amask.data_ptr(), words, self._fr_ptr,
+                                                 None if snap is None else snap.data_ptr(), self._stream()), "w2a_rollout")
         self._keep_pol = keep
         st = self.state()
         out["done"] = st["finished"].bool()  # the terminal step has run (t stops at n_days-1 before AND after it)
@@ -634,6 +637,35 @@ class HeatAlertVecEnv(_VectorEnvBase):
             if self._steps_in_episode >= self._episode_len:
                 self._launch_device_reset(None, self._obs_ptr)
         return out
+
+    def _rollout_posterior_mean(self, p, steps, out, mask, amask, words, snap, st0) -> int:
+        """rollout() with reward_mode="posterior_mean": per day w2a_policy_actions (the policy and counters of
+        k_rollout), w2a_posterior_mean_reward, w2a_step(REWARD_GIVEN). The batch is in lock step (checked by the
+        constructor), so the day and the episode length are those of env 0. Returns the number of days run."""
+        for k in ("return", "alerts", "attempts_over_budget"):
+            out[k].zero_()
+        for m in (mask, amask):
+            if m is not None:
+                m.zero_()
+        t0, n_days, fin = int(st0["t"][0]), int(st0["n_days"][0]), bool(st0["finished"][0])
+        steps = 0 if fin else min(steps, n_days - t0)
+        act = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        lib, h, stream = self._lib, self._h, self._stream()
+        for k in range(steps):
+            _ffi.check(lib.w2a_policy_actions(h, C.byref(p), act.data_ptr(), out["alerts"].data_ptr(),
+                                              out["attempts_over_budget"].data_ptr(),
+                                              None if mask is None else mask.data_ptr(),
+                                              None if amask is None else amask.data_ptr(), words, stream),
+                       "w2a_policy_actions")
+            _ffi.check(lib.w2a_posterior_mean_reward(h, act.data_ptr(), _ffi.ACT_I32, self._rew_ptr, stream),
+                       "w2a_posterior_mean_reward")
+            _ffi.check(self._w2a_step(h, act.data_ptr(), _ffi.ACT_I32, self._obs_ptr, self._rew_ptr, self._done_ptr,
+                                      self._fr_ptr, self._step_flags, stream), "w2a_step")
+            out["return"] += self._reward
+            if snap is not None and t0 + k + 1 == n_days - 2:  # the moment the reference's callbacks read the env
+                snap.copy_(self.state()["episode_return"])
+        self._keep_act = act
+        return steps
 
     @classmethod
     def episode_stats(cls, out: dict) -> dict:
