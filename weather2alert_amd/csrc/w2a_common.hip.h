@@ -155,6 +155,8 @@ struct w2a_env {
   uint4 *prep;           // per-step scratch of the posterior-mean path, inside the same workspace
   const uint32_t *inv;   // sorted position of every env, in the same workspace
   const double *wd;      // fp64 copy of W scaled by -log2(e), in the same workspace
+  const uint4 *tiles;    // tile list of the posterior-mean kernel, in the same workspace
+  const uint32_t *n_tiles;
   int perm_valid;
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };

@@ -307,11 +307,14 @@ static size_t cub_group_bytes(int64_t n) {
 }
 
 static size_t wd_bytes(int32_t S, int32_t n_samples) { return align256((size_t)S * n_samples * 2 * ROWF * sizeof(double)); }
+// tiles of the posterior-mean kernel: at most one partial tile per column on top of n / PMV_THREADS full ones
+static size_t max_tiles(int64_t n, int32_t S) { return (size_t)((n + PMV_THREADS - 1) / PMV_THREADS) + (size_t)S; }
+static size_t tile_bytes(int64_t n, int32_t S) { return align256(16 * max_tiles(n, S)) + 2 * align256(4 * (size_t)S) + 256; }
 
 size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || S <= 0 || n_samples <= 0) return 0;
   return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + wd_bytes(S, n_samples) +
-         align256(cub_group_bytes(num_envs));
+         tile_bytes(num_envs, S) + align256(cub_group_bytes(num_envs));
 }
 
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
@@ -323,6 +326,10 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first two: stay in use after the call
   env->prep = (uint4 *)p;          p += align256(16 * n);
   double *wd = (double *)p;        p += wd_bytes(env->tb.S, env->tb.n_samples);
+  uint4 *tiles = (uint4 *)p;       p += align256(16 * max_tiles(env->n, env->tb.S));
+  uint32_t *col_start = (uint32_t *)p; p += align256(4 * (size_t)env->tb.S);
+  uint32_t *col_end = (uint32_t *)p;   p += align256(4 * (size_t)env->tb.S);
+  uint32_t *n_tiles = (uint32_t *)p;   p += 256;
   uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);  // sort keys, then the inverse permutation (stays in use)
   uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
@@ -333,7 +340,15 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   int bits = 1;
   while ((1 << bits) < env->tb.S) ++bits;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, perm, (int)n, 0, bits, s));
-  // fp64 copy of the coefficient rows, scaled by -log2(e), for the scalar-operand form of the reward kernel
+  // tiles of <= PMV_THREADS sorted positions of one column each
+  HIP_TRY(hipMemsetAsync(col_start, 0, 2 * align256(4 * (size_t)env->tb.S), s));
+  hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k_out, col_start, col_end, env->n);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, col_start, col_end, env->tb.S, tiles, n_tiles);
+  HIP_TRY(hipGetLastError());
+  env->tiles = tiles;
+  env->n_tiles = n_tiles;
+  // fp64 copy of the coefficient rows, scaled by -log2(e), for the lane = env form of the reward kernel
   const int64_t w_count = (int64_t)env->tb.S * env->tb.n_samples * 2 * ROWF;
   hipLaunchKernelGGL(k_pm_wd, dim3((unsigned)((w_count + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float *>(env->tb.W), wd, w_count);
@@ -358,7 +373,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   PosteriorArgs a;
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
-  a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd;
+  a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
 #if W2A_PM_MATRIX
@@ -366,7 +381,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_posterior_mean<7>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
 #else
-  const unsigned grid = (unsigned)(((env->n + PMV_THREADS - 1) / PMV_THREADS + 7) / 8 * 8);
+  const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
   if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean_v<8>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_posterior_mean_v<7>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
 #endif

@@ -43,6 +43,8 @@ struct PosteriorArgs {
   const uint32_t *inv;   // [n] sorted position of every env (inverse of the env ids sorted by coefficient column)
   uint4 *prep;           // [n] per-env record of the day in SORTED order (k_pm_prep -> k_posterior_mean*)
   const double *wd;      // [S * n_samples][2][32] coefficient rows as -log2(e) * W in fp64 (k_pm_wd)
+  const uint4 *tiles;    // tile list of k_posterior_mean_v (k_tile_list)
+  const uint32_t *n_tiles;
   const void *actions;
   int32_t act_dtype;
   float *reward;
@@ -304,18 +306,18 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
 // pays for its fragments (B through LDS with a convert per use, 112-for-100 draw padding, a cross-lane reduction).
 // What the matrix unit does provide is operand delivery, and the vector unit has a second way to get it: gfx90a+
 // DPP on 64-bit operations, row_newbcast:n = lane n of every 16-lane row broadcast to the row. So:
-//   * a wave serves 64 envs of one coefficient column, lane = env; the env's feature row of the day (run-time slots
-//     patched in) sits in registers as 28 (32) doubles;
+//   * a workgroup serves one tile = <= 512 envs of ONE coefficient column (k_tile_list), lane = env; the env's feature
+//     row of the day (run-time slots patched in) sits in registers as 28 (32) doubles;
 //   * the workgroup stages the column's block of a fp64 copy of W that already carries the factor -log2(e) (k_pm_wd,
 //     once per episode) in LDS; per draw every lane reads TWO doubles of the draw's coefficient row, slots (lane & 15)
 //     and 16 + (lane & 15): 8 LDS cycles per wave and draw;
-//   * v_fmac_f64_dpp acc, coef row_newbcast:k, x[k] -- 28 FMAs over two chains, one of them started from the
-//     broadcast bias -- then v_exp_f32 + v_rcp_f32 and one fp64 add: exactly n_samples draws, the sum over draws
-//     lane-local. 37 vector instructions per env-wave and draw.
-// The effectiveness head matters for the few rows with gate * actual = 1 only. The rows of a workgroup are re-ordered
-// so that these sit first in their column segment; after the baseline pass EVERY wave of the workgroup takes the
-// same group of <= 64 such rows and an eighth of the draws with both heads, and the row's owner adds the eight
-// partial sums in a fixed order: the extra work is spread evenly instead of making one wave a straggler.
+//   * v_fmac_f64_dpp acc, coef row_newbcast:k, x[k] -- 28 FMAs in one chain started from the broadcast bias -- then
+//     v_cvt_f32_f64, v_exp_f32, add, v_rcp_f32; four terms are added in f32, the blocks in fp64: exactly n_samples
+//     draws, the sum over draws lane-local. 33 vector instructions per env-wave and draw.
+// The effectiveness head matters for the few rows with gate * actual = 1 only. After the baseline pass their owners
+// publish these rows in LDS, <= 64 at a time, and EVERY wave of the workgroup takes the same group and an eighth of
+// the draws with both heads; the row's owner adds the partial sums in a fixed order: the extra work is spread
+// evenly instead of making one wave a straggler.
 // Every lane of a wave stays active in the draw loops (DPP reads its source lane whatever that lane's own row is).
 #ifndef PMV_THREADS
 #define PMV_THREADS 512
@@ -484,28 +486,66 @@ __device__ __forceinline__ void pmv_widen(float4 (&xf)[KS], double (&ax)[4 * KS]
   }
 }
 
+// Tiles of the lane = env kernel: <= PMV_THREADS consecutive sorted positions of ONE coefficient column, listed once
+// per episode by w2a_group_by_column (k_tile_bounds + k_tile_list). A workgroup then stages exactly one coefficient
+// block and runs one pass; with fixed 512-position ranges a third of the workgroups straddled two columns and ran
+// the two passes one after the other with half their waves idle.
+__global__ void k_tile_bounds(const uint32_t *keys_sorted, uint32_t *col_start, uint32_t *col_end, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys_sorted[i];
+  if (i == 0 || keys_sorted[i - 1] != k) col_start[k] = (uint32_t)i;
+  if (i == n - 1 || keys_sorted[i + 1] != k) col_end[k] = (uint32_t)i + 1u;
+}
+
+// one workgroup: tiles of every column in column order; tiles[j] = (first position, rows, column, 0)
+__global__ __launch_bounds__(1024) void k_tile_list(const uint32_t *col_start, const uint32_t *col_end, int32_t S,
+                                                    uint4 *tiles, uint32_t *n_tiles) {
+  __shared__ uint32_t s_cnt[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (S + 1023) / 1024;
+  const int c0 = min(S, tid * chunk), c1 = min(S, c0 + chunk);
+  uint32_t mine = 0;
+  for (int c = c0; c < c1; ++c) mine += (col_end[c] - col_start[c] + PMV_THREADS - 1) / PMV_THREADS;
+  s_cnt[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan
+    const uint32_t v = tid >= d ? s_cnt[tid - d] : 0u;
+    __syncthreads();
+    s_cnt[tid] += v;
+    __syncthreads();
+  }
+  uint32_t j = s_cnt[tid] - mine;
+  for (int c = c0; c < c1; ++c)
+    for (uint32_t st = col_start[c]; st < col_end[c]; st += PMV_THREADS)
+      tiles[j++] = make_uint4(st, min((uint32_t)PMV_THREADS, col_end[c] - st), (uint32_t)c, 0u);
+  if (tid == 1023) *n_tiles = s_cnt[1023];
+}
+
 template <int KS>
-__global__ __launch_bounds__(PMV_THREADS) void k_posterior_mean_v(const PosteriorArgs a) {
-  constexpr int ROWS = PMV_THREADS;  // sorted positions per workgroup, lane = row
+__global__ __launch_bounds__(PMV_THREADS, 4) void k_posterior_mean_v(const PosteriorArgs a) {
   constexpr int WAVES = PMV_THREADS / 64;
-  __shared__ uint32_t s_col[ROWS];
-  __shared__ uint32_t s_G[ROWS + 1];                // rows with gate * actual = 1 before row r
-  __shared__ uint32_t s_wga[WAVES];
-  __shared__ double sW[W2A_PMV_NPAD][2][ROWF];      // the segment's coefficient block
+  __shared__ uint32_t s_wga[WAVES];                 // per wave: rows with gate * actual = 1
+  __shared__ double sW[W2A_PMV_NPAD][2][ROWF];      // the column's coefficient block
   __shared__ float4 s_ax[64][KS];                   // effectiveness phase: the rows of one group, as f32
   __shared__ double s_part[WAVES][64];              // effectiveness phase: per-wave, per-lane partial sums
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15;
-  // XCD k walks the k-th contiguous eighth of the sorted positions: the 2-3 workgroups of a coefficient column run
-  // on one XCD and its block comes out of that XCD's L2 after the first of them has staged it
-  const int64_t pos0 = (int64_t)logical_block(blockIdx.x, gridDim.x >> 3) * ROWS;
-  if (pos0 >= a.n) return;  // the grid is rounded up to a multiple of 8
-  // ---- set-up: the row's record (coalesced), its feature row of the day (requested at once, kept as f32 for the
-  // whole kernel), and the count of effectiveness rows before it
-  uint4 rec = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);  // past the end: feature row 0 (a valid address), never stored
-  if (pos0 + tid < a.n) rec = a.prep[pos0 + tid];   // x feature row, y run-time fields, z column, w env id
+  // XCD k walks the k-th contiguous eighth of the tile list: the 2-3 tiles of a coefficient column run on one XCD and
+  // its block comes out of that XCD's L2 after the first of them has staged it
+  const uint32_t n_tiles = *a.n_tiles, per_xcd = (n_tiles + 7u) >> 3;
+  const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles) return;  // the grid covers the largest possible tile count
+  const uint4 tl = a.tiles[tile];  // first sorted position, rows, column
+  const uint32_t col = __builtin_amdgcn_readfirstlane(tl.z);
+  const int rows = (int)__builtin_amdgcn_readfirstlane(tl.y);
+  const int n_samples = a.tb.n_samples;
+  // ---- the row's record (coalesced) and its feature row of the day (requested at once, kept as f32 for the whole
+  // kernel); rows past the end of the tile: feature row 0 (a valid address), never stored
+  uint4 rec = make_uint4(0u, 0u, 0u, 0u);  // x feature row, y run-time fields, z column, w env id
+  if (tid < rows) rec = a.prep[tl.x + tid];
   float4 xf[KS];
   {
     const float4 *xp = a.tb.X + (rec.x >> 2);
@@ -515,102 +555,82 @@ __global__ __launch_bounds__(PMV_THREADS) void k_posterior_mean_v(const Posterio
                               (float)((rec.y >> 11) & 15u));  // slots 24..27: the run-time fields of k_pm_prep
   }
   const uint32_t ga = (rec.y >> 15) & 1u;
-  uint32_t G;
-  {
-    const uint64_t bal = __ballot(ga != 0);
-    G = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    s_col[tid] = rec.z;
-    if (lane == 0) s_wga[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    for (int w = 0; w < wave; ++w) G += s_wga[w];
-    s_G[tid] = G;
-    if (tid == ROWS - 1) s_G[ROWS] = G + ga;
-    __syncthreads();
-  }
-  const int n_samples = a.tb.n_samples;
+  const uint64_t bal = __ballot(ga != 0);
+  if (lane == 0) s_wga[wave] = (uint32_t)__popcll(bal);
   double sum = 0.0;
-  // ---- column segments of the workgroup's rows (sorted by column: a segment is a contiguous run; one, sometimes
-  // two, at bench sizes). The segment's coefficient block is staged in LDS once per pass of <= W2A_PMV_NPAD draws.
-  int seg = 0;
-  while (seg < ROWS) {
-    // (LDS reads of wave-uniform addresses: readfirstlane tells the compiler the values are scalar)
-    const uint32_t col = __builtin_amdgcn_readfirstlane(s_col[seg]);
-    if (col == 0xFFFFFFFFu) break;
-    int lo = seg + 1, hi = ROWS;      // seg_end = first row whose column is larger (binary search)
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (__builtin_amdgcn_readfirstlane(s_col[mid]) > col) hi = mid; else lo = mid + 1;
+  uint32_t G = 0;      // rows with gate * actual = 1 before this one
+  int n_eff = 0;       // ... in the whole tile
+  for (int n0 = 0; n0 < n_samples; n0 += W2A_PMV_NPAD) {
+    const int draws = min(W2A_PMV_NPAD, n_samples - n0);
+    __syncthreads();  // previous users of sW are done
+    // stage wd[(col * n_samples + n0 + s)][head][slot] -> sW[s][head][slot]: 16-B loads and stores, coalesced
+    {
+      const uint4 *src = reinterpret_cast<const uint4 *>(a.wd + ((size_t)col * n_samples + n0) * (2 * ROWF));
+      uint4 *dst = reinterpret_cast<uint4 *>(&sW[0][0][0]);
+      for (int idx = tid; idx < draws * (2 * ROWF / 2); idx += PMV_THREADS) dst[idx] = src[idx];
     }
-    const int seg_end = lo;
-    const uint32_t g_seg = __builtin_amdgcn_readfirstlane(s_G[seg]);
-    const int n_eff = (int)(__builtin_amdgcn_readfirstlane(s_G[seg_end]) - g_seg);  // rows that need the effectiveness head
-    const bool in_seg = tid >= seg && tid < seg_end;
-    const bool wave_in = seg < 64 * (wave + 1) && seg_end > 64 * wave;  // wave-uniform
-    for (int n0 = 0; n0 < n_samples; n0 += W2A_PMV_NPAD) {
-      const int draws = min(W2A_PMV_NPAD, n_samples - n0);
-      __syncthreads();  // previous users of sW are done
-      // stage wd[(col * n_samples + n0 + s)][head][slot] -> sW[s][head][slot]: 16-B loads and stores, coalesced
-      {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.wd + ((size_t)col * n_samples + n0) * (2 * ROWF));
-        uint4 *dst = reinterpret_cast<uint4 *>(&sW[0][0][0]);
-        for (int idx = tid; idx < draws * (2 * ROWF / 2); idx += PMV_THREADS)
-          if (n_eff || !((idx >> 4) & 1)) dst[idx] = src[idx];  // 16 uint4 per head row
+    __syncthreads();
+    if (n0 == 0) {
+      G = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = s_wga[w];
+        G += w < wave ? c : 0u;
+        n_eff += (int)c;
+      }
+      n_eff = __builtin_amdgcn_readfirstlane(n_eff);
+    }
+    double contrib = 0.0;
+    // baseline pass: the wave's own rows, every draw
+    if (64 * wave < rows) {
+      double ax[4 * KS];
+      pmv_widen<KS>(xf, ax);
+      contrib = pmv_draws<KS>(sW, draws, l15, ax);
+    }
+    // effectiveness phase, groups of <= 64 rows: their owners publish the rows, then EVERY wave takes an eighth of
+    // the draws with both heads. A group of cnt rows fills R = ceil(cnt / 16) DPP rows of a wave; the wave's other
+    // DPP rows work on other draws of its eighth at the same time (P = 4 / R draws in flight).
+    for (int grp = 0; grp < n_eff; grp += 64) {
+      const int cnt = min(64, n_eff - grp);
+      const int j_own = (int)G - grp;  // this thread's row is row j_own of the group (if it is one)
+      const bool own = ga && j_own >= 0 && j_own < 64;
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) s_ax[j_own][q] = xf[q];
       }
       __syncthreads();
-      double contrib = 0.0;
-      // baseline pass: the wave's own rows, every draw (rows of other segments compute a value that is dropped)
-      if (wave_in) {
+      const int R = (cnt + 15) >> 4, P = R == 1 ? 4 : (R == 2 ? 2 : 1);
+      const int drow = lane >> 4;                // DPP row of the lane
+      const int j = l15 + 16 * (drow % R);       // group row served by the lane
+      const int sub = drow / R;                  // which of the P draws in flight
+      const int d0 = wave * draws / WAVES, d1 = (wave + 1) * draws / WAVES;
+      double part = 0.0;
+      {
+        float4 ef[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) ef[q] = s_ax[j < cnt ? j : 0][q];
         double ax[4 * KS];
-        pmv_widen<KS>(xf, ax);
-        contrib = pmv_draws<KS>(sW, draws, l15, ax);
-      }
-      // effectiveness phase, groups of <= 64 rows: their owners publish the rows, then EVERY wave takes an eighth of
-      // the draws with both heads. A group of cnt rows fills R = ceil(cnt / 16) DPP rows of a wave; the wave's other
-      // DPP rows work on other draws of its eighth at the same time (P = 4 / R draws in flight).
-      for (int grp = 0; grp < n_eff; grp += 64) {
-        const int cnt = min(64, n_eff - grp);
-        const int j_own = (int)(G - g_seg) - grp;  // this thread's row is row j_own of the group (if it is one)
-        const bool own = in_seg && ga && j_own >= 0 && j_own < 64;
-        if (own) {
-#pragma unroll
-          for (int q = 0; q < KS; ++q) s_ax[j_own][q] = xf[q];
-        }
-        __syncthreads();
-        const int R = (cnt + 15) >> 4, P = R == 1 ? 4 : (R == 2 ? 2 : 1);
-        const int drow = lane >> 4;                // DPP row of the lane
-        const int j = l15 + 16 * (drow % R);       // group row served by the lane
-        const int sub = drow / R;                  // which of the P draws in flight
-        const int d0 = wave * draws / WAVES, d1 = (wave + 1) * draws / WAVES;
-        double part = 0.0;
-        {
-          float4 ef[KS];
-#pragma unroll
-          for (int q = 0; q < KS; ++q) ef[q] = s_ax[j < cnt ? j : 0][q];
-          double ax[4 * KS];
-          pmv_widen<KS>(ef, ax);
+        pmv_widen<KS>(ef, ax);
 #pragma unroll 1
-          for (int s = d0; s < d1; s += P) {       // uniform trip count; lanes past the slice redo its last draw
-            const int sl = s + sub;
-            const float t = pmv_term<KS, true>(sW, sl < d1 ? sl : d1 - 1, l15, ax);
-            part += (sl < d1 && sub < P) ? (double)t : 0.0;
-          }
-        }
-        s_part[wave][lane] = part;
-        __syncthreads();
-        if (own) {
-          double t = 0.0;
-#pragma unroll 1
-          for (int w = 0; w < WAVES; ++w)
-#pragma unroll 1
-            for (int p = 0; p < P; ++p) t += s_part[w][(j_own & 15) + 16 * ((j_own >> 4) + R * p)];
-          contrib = t;  // replaces the baseline-only value
+        for (int s = d0; s < d1; s += P) {       // uniform trip count; lanes past the slice redo its last draw
+          const int sl = s + sub;
+          const float t = pmv_term<KS, true>(sW, sl < d1 ? sl : d1 - 1, l15, ax);
+          part += (sl < d1 && sub < P) ? (double)t : 0.0;
         }
       }
-      sum += in_seg ? contrib : 0.0;
+      s_part[wave][lane] = part;
+      __syncthreads();
+      if (own) {
+        double t = 0.0;
+#pragma unroll 1
+        for (int w = 0; w < WAVES; ++w)
+#pragma unroll 1
+          for (int p = 0; p < P; ++p) t += s_part[w][(j_own & 15) + 16 * ((j_own >> 4) + R * p)];
+        contrib = t;  // replaces the baseline-only value
+      }
     }
-    seg = seg_end;
+    sum += contrib;
   }
-  if (rec.z != 0xFFFFFFFFu) a.reward[rec.w] = (float)(-(1000.0 / 152.0) * sum / (double)n_samples);
+  if (tid < rows) a.reward[rec.w] = (float)(-(1000.0 / 152.0) * sum / (double)n_samples);
 }
 
 #endif  // W2A_POSTERIOR_HIP_H
