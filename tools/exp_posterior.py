@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time of reward_mode="posterior_mean" at 1 M envs (k_pm_prep + k_posterior_mean_v + k_step64<given>).
 Build variants (W2A_CXXFLAGS, see tools/exp_pm_variants.sh / exp_pm_trace.sh): -DW2A_PM_MATRIX=1 the fp64-MFMA form,
--DW2A_PMV_CHAINS=2, -DW2A_PMV_NPAD=<draws staged per pass>, -DPMV_THREADS=<256|512|1024>,
+-DW2A_PMV_NPAD=<draws staged per pass>, -DPMV_THREADS=<256|512|1024>,
 -DW2A_PMV_DEBUG_DRAWS=<n> (caps the baseline draw loop: timing only, results wrong). DESIGN.md section 4."""
 import sys, torch, json
 sys.path.insert(0,'.')

@@ -67,8 +67,12 @@ __global__ void k_pm_prep(const PosteriorArgs a) {
   const Day d = derive_day(h, c, load_action_raw(a.actions, a.act_dtype, e));
   const uint32_t xrow = (d.t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b) * ROWF;
   const float4 rt = runtime_fields(d);
-  // effectiveness enters through eff * gate * actual (env.py:218-221): slot 30 of the row is the 0/1 gate flag
-  const uint32_t ga = (d.actual && reinterpret_cast<const float *>(a.tb.X)[xrow + 30] > 0.5f) ? 1u : 0u;
+  // effectiveness enters through eff * gate * actual (env.py:218-221): slot 30 of the row is the 0/1 gate flag, also
+  // available as a bitmap of the day (1 KB, cache-resident) when the tables carry one
+  uint32_t ga = 0u;
+  if (d.actual)
+    ga = a.tb.gate_bits ? (a.tb.gate_bits[(size_t)d.t * a.tb.gate_words + (c.b >> 5)] >> (c.b & 31u)) & 1u
+                        : (reinterpret_cast<const float *>(a.tb.X)[xrow + 30] > 0.5f ? 1u : 0u);
   const uint32_t rem = (uint32_t)min(max((int32_t)rt.z, 0), 65535);
   const uint32_t pk = (uint32_t)rt.x | ((uint32_t)rt.y << 1) | ((uint32_t)rt.w << 11) | (ga << 15) | (rem << 16);
   a.prep[a.inv[e]] = make_uint4(xrow, pk, W_COL(c.c), e);
@@ -322,9 +326,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
 #ifndef PMV_THREADS
 #define PMV_THREADS 512
 #endif
-#ifndef W2A_PMV_CHAINS
-#define W2A_PMV_CHAINS 1           // accumulation chains per logit (A/B: 2 = two interleaved chains, 2 more instructions)
-#endif
 #ifndef W2A_PMV_NPAD
 #define W2A_PMV_NPAD 112           // draws staged in LDS per pass
 #endif
@@ -333,50 +334,10 @@ __global__ void k_pm_wd(const float *W, double *wd, int64_t count) {
   if (i < count) wd[i] = -1.4426950408889634 * (double)W[i];
 }
 
-// z0, z1 += sum_k coef[k] * x[k] for slots held by `b` (lane n of each 16-lane row holds slot base + n). The leading
-// s_nop covers the VALU-write -> DPP-read hazard should the compiler have just moved `b` between registers.
-__device__ __forceinline__ void pmv_fma16(double &z0, double &z1, double b, const double *x) {
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(z0), "+v"(z1)
-      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
-        "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
-}
-__device__ __forceinline__ void pmv_fma12(double &z0, double &z1, double b, const double *x) {
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(z0), "+v"(z1)
-      : "v"(b), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
-        "v"(x[9]), "v"(x[10]), "v"(x[11]));
-}
-// single-chain forms (W2A_PMV_CHAINS == 1): two instructions fewer per draw; the dependent FMAs of one wave are
-// interleaved with those of the SIMD's other waves
+// z += sum_k coef[k] * x[k] for the slots held by `b` (lane n of each 16-lane row holds slot base + n): one chain of
+// dependent FMAs, which the SIMD's other waves interleave with theirs (two chains cost two more instructions per draw
+// and measured 9 % slower). The leading s_nop covers the VALU-write -> DPP-read hazard should the compiler have
+// just moved `b` between registers.
 __device__ __forceinline__ void pmv_fma16(double &z0, double b, const double *x) {
   asm("s_nop 1\n\t"
       "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
@@ -427,25 +388,11 @@ __device__ __forceinline__ double pmv_bias(double b) {
 template <int KS>
 __device__ __forceinline__ float pmv_logit(const double *sWd, int l15, const double (&ax)[4 * KS]) {
   const double b0 = sWd[l15], b1 = sWd[16 + l15];
-#if W2A_PMV_CHAINS == 1
-  double z = KS == ROWF / 4 ? 0.0 : pmv_bias(b1);
+  double z = KS == ROWF / 4 ? 0.0 : pmv_bias(b1);  // all 32 slots (slot 29 of the row holds 1.0) / 0..27 + bias
   pmv_fma16(z, b0, &ax[0]);
   if (KS == ROWF / 4) pmv_fma16(z, b1, &ax[16]);
   else pmv_fma12(z, b1, &ax[16]);
   return (float)z;
-#else
-  double z0, z1 = 0.0;
-  if (KS == ROWF / 4) {  // all 32 slots (slot 29 of the row holds 1.0)
-    z0 = 0.0;
-    pmv_fma16(z0, z1, b0, &ax[0]);
-    pmv_fma16(z0, z1, b1, &ax[16]);
-  } else {               // slots 0..27, chain 0 starts from the bias
-    z0 = pmv_bias(b1);
-    pmv_fma16(z0, z1, b0, &ax[0]);
-    pmv_fma12(z0, z1, b1, &ax[16]);
-  }
-  return (float)(z0 + z1);
-#endif
 }
 
 // sigmoid(zb) [* (1 - sigmoid(ze))] of the lane's env for staged draw s; sW = [draw][head][slot]
