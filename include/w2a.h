@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 6
+#define W2A_ABI_VERSION 7
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -232,6 +232,13 @@ typedef struct w2a_policy {
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
                 int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
                 float *last_return, float *ret_snapshot, void *stream);
+/* Optional, speed only: let w2a_rollout visit the envs in the order of their feature rows (envs that share a
+ * (county, year) sit in the same wave and read the same table lines every day). Results are those of any other
+ * order -- per-env outputs, RNG streams and state stay indexed by env id. Call after a reset (the order of an
+ * earlier episode stays valid as a permutation, it is just no longer sorted). workspace: caller-owned,
+ * w2a_rollout_order_workspace_bytes(num_envs) bytes, 256-B aligned, must stay alive while w2a_rollout is used. */
+size_t w2a_rollout_order_workspace_bytes(int64_t num_envs);
+int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One day of a built-in policy: actions i32 [n] of every env from its pre-step state -- the same policy evaluation,
  * lagging observation and budget gate as w2a_rollout (finished envs get action 0) -- for policy loops whose step is

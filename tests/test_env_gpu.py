@@ -554,6 +554,36 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     env.close()
 
 
+def test_rollout_visiting_order_does_not_change_results(dev):
+    """w2a_rollout_order only changes which lane group serves which env (envs that share a feature row sit together):
+    every per-env output and the state are bit-identical to the index-order rollout, also when the order stems from an
+    earlier episode (still a permutation, no longer sorted)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=30, years=[2006, 2007], n_samples=6, seed=17, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    n = 5000 + 3
+    pol = dict(kind="bernoulli", p=0.2, seed=5)
+    a = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, rollout_order=True)
+    b = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, rollout_order=False)
+    a.reset(seed=3)
+    b.reset(seed=3)
+    for ep in range(2):
+        oa, ob = a.rollout(pol, n_steps=60, alert_mask=True), b.rollout(pol, n_steps=60, alert_mask=True)
+        for k in ("return", "alerts", "attempts_over_budget", "alert_days", "attempt_days"):
+            assert torch.equal(oa[k], ob[k]), k
+        a._order_stale = False  # second half of the episode and the next episode on the first episode's order
+        oa, ob = a.rollout(pol, alert_mask=True), b.rollout(pol, alert_mask=True)
+        for k in ("return", "alerts", "final_return", "alert_days", "return_snapshot"):
+            assert torch.equal(oa[k], ob[k]), k
+        a._order_stale = False
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    a.close()
+    b.close()
+
+
 def test_partial_rollouts_report_done_from_the_finished_bit(dev):
     """A rollout that stops one day short leaves t = n_days-1 with the terminal step still to run: done must be
     False and the running return must not be taken for a final one; one more day finishes every env."""

@@ -157,6 +157,7 @@ struct w2a_env {
   const double *wd;      // fp64 copy of W scaled by -log2(e), in the same workspace
   const uint4 *tiles;    // tile list of the posterior-mean kernel, in the same workspace
   const uint32_t *n_tiles;
+  const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };

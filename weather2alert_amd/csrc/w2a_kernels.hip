@@ -51,6 +51,24 @@
     if (_e != hipSuccess) return fail(W2A_ERR_HIP, #expr ": %s", hipGetErrorString(_e)); \
   } while (0)
 
+// k_rollout is compiled per (policy kind, day bitmaps wanted, corrected-semantics flags set)
+template <int KIND>
+static void launch_rollout_kind(bool masks, bool fixes, unsigned grid, hipStream_t s, const RolloutArgs &a) {
+  if (masks && fixes) hipLaunchKernelGGL((k_rollout<KIND, true, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+  else if (masks) hipLaunchKernelGGL((k_rollout<KIND, true, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+  else if (fixes) hipLaunchKernelGGL((k_rollout<KIND, false, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+  else hipLaunchKernelGGL((k_rollout<KIND, false, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+static void launch_rollout(int kind, bool masks, bool fixes, unsigned grid, hipStream_t s, const RolloutArgs &a) {
+  switch (kind) {
+    case W2A_POLICY_ALWAYS: launch_rollout_kind<W2A_POLICY_ALWAYS>(masks, fixes, grid, s, a); break;
+    case W2A_POLICY_BERNOULLI: launch_rollout_kind<W2A_POLICY_BERNOULLI>(masks, fixes, grid, s, a); break;
+    case W2A_POLICY_THRESHOLD: launch_rollout_kind<W2A_POLICY_THRESHOLD>(masks, fixes, grid, s, a); break;
+    case W2A_POLICY_TABLE: launch_rollout_kind<W2A_POLICY_TABLE>(masks, fixes, grid, s, a); break;
+    default: launch_rollout_kind<W2A_POLICY_NEVER>(masks, fixes, grid, s, a); break;
+  }
+}
+
 extern "C" {
 
 int w2a_abi_version(void) { return W2A_ABI_VERSION; }
@@ -122,6 +140,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
+  h->order = nullptr;
   h->prep = nullptr;
   h->perm_valid = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
@@ -408,6 +427,32 @@ int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
   return W2A_OK;
 }
 
+size_t w2a_rollout_order_workspace_bytes(int64_t num_envs) {
+  if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
+  return align256(4 * (size_t)num_envs) * 4 + align256(cub_group_bytes(num_envs));
+}
+
+int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_order: NULL argument");
+  if (workspace_bytes < w2a_rollout_order_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace too small");
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace must be 256-B aligned");
+  const size_t n = (size_t)env->n;
+  char *p = (char *)workspace;
+  uint32_t *order = (uint32_t *)p; p += align256(4 * n);  // stays in use after the call
+  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
+  uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
+  uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
+  size_t cub_bytes = cub_group_bytes(env->n);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rollout_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
+  HIP_TRY(hipGetLastError());
+  int bits = 1;
+  while ((1ll << bits) < (int64_t)env->tb.S_w * env->tb.Y) ++bits;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, order, (int)n, 0, bits, s));
+  env->order = order;
+  return W2A_OK;
+}
+
 int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out, int32_t *alerts_out,
                 int32_t *attempts_over_budget, uint32_t *alert_mask, uint32_t *attempt_mask, int32_t mask_words,
                 float *last_return, float *ret_snapshot, void *stream) {
@@ -432,10 +477,11 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   a.n_steps = n_steps; a.ret_out = ret_out; a.alerts_out = alerts_out; a.attempts_over_budget = attempts_over_budget;
   a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words; a.last_return = last_return;
   a.ret_snapshot = ret_snapshot;
+  a.order = env->order;
   hipStream_t s = (hipStream_t)stream;
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_rollout, dim3(grid_for(env->n)), dim3(BLOCK), 0, s, a);
+  launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }

@@ -28,18 +28,29 @@ struct RolloutArgs {
   float *last_return;
   float *ret_snapshot;            // [n] running episode return after the step that leaves t == n_days - 2 (nullable):
                                   // what the reference's logging callbacks read (callbacks.py:47-48,128-132)
+  const uint32_t *order;          // [n] visiting order (a permutation of the env ids; nullable = identity): w2a_rollout_order
+                                  // sorts the envs by feature row, so the 16 envs of a wave read one or two table lines
+                                  // per day instead of 16 (the day loop is otherwise bound by those reads: 19 GB of
+                                  // fabric traffic per 1 M-env episode, profiles/r02/rollout_counters.log)
 };
 
+__global__ void k_rollout_keys(const uint4 *cold, uint32_t *keys, uint32_t *idx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = cold[i].x;  // feature row of the episode: county_w * Y + year_i
+  idx[i] = (uint32_t)i;
+}
+
 // the built-in policies on what the reference's agent would see (shared by k_rollout and k_policy_actions)
-__device__ __forceinline__ int32_t policy_action(const w2a_policy &pol, uint64_t pstream, uint32_t t, int32_t rem_now,
-                                                 float feat) {
+__device__ __forceinline__ int32_t policy_action(int32_t kind, const w2a_policy &pol, uint64_t pstream, uint32_t t,
+                                                 int32_t rem_now, float feat) {
   int32_t act = 0;
-  if (pol.kind == W2A_POLICY_ALWAYS) act = 1;
-  else if (pol.kind == W2A_POLICY_BERNOULLI) {
+  if (kind == W2A_POLICY_ALWAYS) act = 1;
+  else if (kind == W2A_POLICY_BERNOULLI) {
     const uint32_t u = (uint32_t)(w2a_mix64(pstream + (uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull) >> 32);
     act = ((float)u * 2.3283064365386963e-10f < pol.p) ? 1 : 0;
-  } else if (pol.kind == W2A_POLICY_THRESHOLD) act = (feat > pol.threshold) ? 1 : 0;
-  else if (pol.kind == W2A_POLICY_TABLE) {
+  } else if (kind == W2A_POLICY_THRESHOLD) act = (feat > pol.threshold) ? 1 : 0;
+  else if (kind == W2A_POLICY_TABLE) {
     int32_t rr = rem_now < 0 ? 0 : (rem_now >= pol.table_R ? pol.table_R - 1 : rem_now);
     act = pol.table[(size_t)t * pol.table_R + rr] ? 1 : 0;
   }
@@ -47,6 +58,9 @@ __device__ __forceinline__ int32_t policy_action(const w2a_policy &pol, uint64_t
   return act;
 }
 
+// Compiled per policy kind, with / without the day bitmaps, with / without corrected-semantics flags: the day loop is
+// bound by instruction issue, and these wave-uniform choices otherwise cost branches and register moves every day.
+template <int KIND, bool MASKS, bool FIXES>
 __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -58,7 +72,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   if (wave_env0 >= a.n) return;
   const int64_t env = wave_env0 + grp;
   const bool valid = env < a.n;
-  const uint32_t e = (uint32_t)(valid ? env : (a.n - 1));
+  const uint32_t slot = (uint32_t)(valid ? env : (a.n - 1));
+  const uint32_t e = a.order ? a.order[slot] : slot;  // the env this lane group serves
   uint4 c2, hot;
   load_step_state(a.st, e, c2, hot);
   const uint4 cold = load_cold(a.st, e);
@@ -91,13 +106,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
   bool snapped = false;
   // feature the policy sees on its first day here: row of day max(t-1, 0) (lagging observation, Q6)
   float feat = 0.0f;
-  if (a.pol.kind == W2A_POLICY_THRESHOLD)
+  if (KIND == W2A_POLICY_THRESHOLD)
     feat = Xf[((size_t)((a.pol.obs_lag && t > 0 ? t - 1 : t) * rows_per_day + cold.x)) * ROWF + a.pol_slot];
   bool active = !fin && valid;
   for (int s = 0; s < a.n_steps; ++s) {
     if (!__any(active)) break;
     // ---- policy
-    const int32_t act = policy_action(a.pol, pstream, t, budget - (int32_t)used, feat);
+    const int32_t act = policy_action(KIND, a.pol, pstream, t, budget - (int32_t)used, feat);
     // ---- env.py:242-250
     const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
     const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
@@ -107,8 +122,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     float4 x[QUADS];
 #pragma unroll
     for (int q = 0; q < QUADS; ++q) x[q] = a.tb.X[day_row * (ROWF / 4) + l * QUADS + q];
-    const float today = (a.pol.kind == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
-    const uint32_t fx = a.tb.fixes;
+    const float today = (KIND == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    const uint32_t fx = FIXES ? a.tb.fixes : 0u;
     const float f_a2w = (float)__popc(hist2);
     if (l == RT_QUAD / QUADS)
       x[RT_QUAD % QUADS] = make_float4((t > 0) ? (float)((fx & W2A_FIX_LAG) ? last : actual) : 0.0f, (float)streak,
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
       ret_total += r;
       alerts += (int32_t)actual;
       over += (act == 1 && atb_s) ? 1 : 0;
-      if (a.alert_mask && actual) {
+      if (MASKS && a.alert_mask && actual) {
         const uint32_t wi = t >> 5;
         if (wi != mask_idx) {
           if (mask_idx != 0xFFFFFFFFu && l == 0 && mask_idx < (uint32_t)a.mask_words)
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
         }
         mask_word |= 1u << (t & 31);
       }
-      if (a.attempt_mask && act == 1) {
+      if (MASKS && a.attempt_mask && act == 1) {
         const uint32_t wi = t >> 5;
         if (wi != att_idx) {
           if (att_idx != 0xFFFFFFFFu && l == 0 && att_idx < (uint32_t)a.mask_words)
@@ -155,14 +170,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
         }
         att_word |= 1u << (t & 31);
       }
-      if ((done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
+      if (MASKS && (done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
       used = used2; hist = hist2; last = actual; atb = atb_s;
       if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
       else { fin = true; active = false; }
       feat = a.pol.obs_lag ? today : feat;
     }
     // lag 1 (faithful): the next decision sees today's row; lag 0 needs tomorrow's row
-    if (a.pol.kind == W2A_POLICY_THRESHOLD && !a.pol.obs_lag && active)
+    if (KIND == W2A_POLICY_THRESHOLD && !a.pol.obs_lag && active)
       feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
   }
   if (valid && l == 0) {
@@ -171,11 +186,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
     if (a.ret_out) a.ret_out[e] = ret;
     if (a.alerts_out) a.alerts_out[e] = alerts;
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
-    if (a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+    if (MASKS && a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
       a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
-    if (a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+    if (MASKS && a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
       a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
-    if (a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
+    if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
   }
 }
@@ -219,7 +234,7 @@ __global__ void k_policy_actions(const PolicyArgs a) {
       feat = reinterpret_cast<const float *>(a.tb.X)[((size_t)tt * rows_per_day + cold.x) * ROWF + a.pol_slot];
     }
     const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
-    act = policy_action(a.pol, pstream, t, budget - (int32_t)used, feat);
+    act = policy_action(a.pol.kind, a.pol, pstream, t, budget - (int32_t)used, feat);
     const bool atb = (int32_t)used == budget;
     const bool actual = act == 1 && !atb;
     if (a.alerts && actual) a.alerts[e] += 1;

@@ -69,6 +69,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          alert_lag1 is yesterday's action), "penalty" (Q5: -1 for an alert attempted at budget),
                          "obs" (Q6: step() returns the next day's row), "augment" (Q8: the drawn similar county
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
+    rollout_order        True (default): rollout() lets the kernel visit the envs in the order of their feature rows
+                         (w2a_rollout_order, one sort per episode); outputs are indexed by env id either way.
     reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
                          "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
@@ -110,6 +112,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         fixes: set | list | None = None,
         step_kernel: Literal["auto", "classic", "wide"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
+        rollout_order: bool = True,
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -156,6 +159,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if reward_mode == "posterior_mean" and (self.fixes or step_kernel == "classic"):
             raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
+        self.rollout_order = bool(rollout_order)  # rollout() visits the envs in feature-row order (speed only; A/B)
+        self._order_stale = True
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
         if episode_order == "sorted" and seed_mode != "device":
@@ -197,6 +202,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._fr_ptr = self._final_return.data_ptr()
         self._done_bool = self._done.view(torch.bool)
         self._sort_ws = None
+        self._order_ws = None
         self._group_ws = None
         if reward_mode == "posterior_mean":
             with torch.cuda.device(dev):
@@ -519,6 +525,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
 
     def _regroup(self):
         """posterior_mean: env ids sorted by coefficient column for the grouped GEMM; after EVERY reset."""
+        self._order_stale = True  # rollout(): the visiting order by feature row belongs to the previous episode
         if self._group_ws is not None:
             if max(int(self.ct.B0.max()), int(self._ctor_budget or 0), int(self._last_opts.get("budget") or 0)) > 65535:
                 raise ValueError("reward_mode='posterior_mean' packs remaining_budget into 16 bits: budgets <= 65535")
@@ -611,6 +618,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
         snap = torch.full((n,), float("nan"), dtype=torch.float32, device=dev) if alert_mask else None
         st0 = self.state() if (alert_mask or self._pm) else None
         with torch.cuda.device(dev):
+            if not self._pm and getattr(self, "_order_stale", True) and self.rollout_order:
+                if self._order_ws is None:
+                    self._order_ws = torch.empty(self._lib.w2a_rollout_order_workspace_bytes(n), dtype=torch.uint8, device=dev)
+                _ffi.check(self._lib.w2a_rollout_order(self._h, self._order_ws.data_ptr(), self._order_ws.numel(),
+                                                       self._stream()), "w2a_rollout_order")
+                self._order_stale = False
             if self._pm:
                 steps = self._rollout_posterior_mean(p, steps, out, mask, amask, words, snap, st0)
             else:
