@@ -540,6 +540,22 @@ def main():
                         "f32 sigmoid / gate / mean; the effectiveness head only for rows with an open-gate alert; time "
                         "includes the pre-pass and the step kernel that consumes the reward"}
             e4.close()
+            # (3b) on-device policy rollout: one launch = one whole episode for every env
+            e6 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment)
+            e6.reset(seed=args.seed)
+            rpol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
+            e6.rollout(rpol)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                e6.rollout(rpol)
+            torch.cuda.synchronize()
+            dt_r = (time.perf_counter() - t0) / 5
+            out["on_device_rollout"] = {
+                "ms_per_episode": dt_r * 1e3, "value": n * ct.T / dt_r, "unit": "env-steps/s",
+                "note": "threshold policy evaluated in the kernel, 153 days per launch, envs visited in feature-row "
+                        "order (w2a_rollout_order, sort included), no observations written"}
+            e6.close()
             # (4) the single-GPU rate of the multi-GPU default workload (configs[4] = nn_full_medicare_all shape), so
             # that `--gpus N` values have their own N = 1 denominator in this file
             if args.workload == "configs2":
