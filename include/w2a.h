@@ -236,8 +236,9 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
  * (county, year) sit in the same wave and read the same table lines every day). Results are those of any other
  * order -- per-env outputs, RNG streams and state stay indexed by env id. Call after a reset (the order of an
  * earlier episode stays valid as a permutation, it is just no longer sorted). workspace: caller-owned,
- * w2a_rollout_order_workspace_bytes(num_envs) bytes, 256-B aligned, must stay alive while w2a_rollout is used. */
-size_t w2a_rollout_order_workspace_bytes(int64_t num_envs);
+ * w2a_rollout_order_workspace_bytes(num_envs, S_w * Y) bytes, 256-B aligned, must stay alive while w2a_rollout is
+ * used. */
+size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows);
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One day of a built-in policy: actions i32 [n] of every env from its pre-step state -- the same policy evaluation,

@@ -24,7 +24,7 @@ int main(void) {
   if (w2a_policy_actions(NULL, &p, NULL, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 10;
   if (w2a_set_semantics(NULL, W2A_FIX_ALL) != W2A_ERR_ARG) return 8;
   if (w2a_sort_workspace_bytes(0) != 0) return 9;
-  if (w2a_rollout_order_workspace_bytes(0) != 0 || w2a_rollout_order_workspace_bytes(1000) < 4 * 4 * 1000) return 11;
+  if (w2a_rollout_order_workspace_bytes(0, 10) != 0 || w2a_rollout_order_workspace_bytes(1000, 10) < 4 * 1000) return 11;
   if (w2a_rollout_order(NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 12;
   printf("w2a C ABI v%d ok, sizeof(w2a_tables)=%zu\n", w2a_abi_version(), sizeof(w2a_tables));
   return 0;

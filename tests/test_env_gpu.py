@@ -555,8 +555,9 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
 
 
 def test_rollout_visiting_order_does_not_change_results(dev):
-    """w2a_rollout_order only changes which lane group serves which env (envs that share a feature row sit together):
-    every per-env output and the state are bit-identical to the index-order rollout, also when the order stems from an
+    """w2a_rollout_order only changes which lane serves which env (envs that share a feature row sit together) and
+    lets the lane = env form of the day loop run: integer outputs and state are identical to the index-order rollout
+    (4 lanes per env), float outputs agree to the order of the fp64 additions -- also when the order stems from an
     earlier episode (still a permutation, no longer sorted)."""
     from weather2alert_amd import HeatAlertVecEnv
 
@@ -570,16 +571,22 @@ def test_rollout_visiting_order_does_not_change_results(dev):
     b.reset(seed=3)
     for ep in range(2):
         oa, ob = a.rollout(pol, n_steps=60, alert_mask=True), b.rollout(pol, n_steps=60, alert_mask=True)
-        for k in ("return", "alerts", "attempts_over_budget", "alert_days", "attempt_days"):
+        for k in ("alerts", "attempts_over_budget", "alert_days", "attempt_days"):
             assert torch.equal(oa[k], ob[k]), k
+        torch.testing.assert_close(oa["return"], ob["return"], rtol=1e-6, atol=1e-5)
         a._order_stale = False  # second half of the episode and the next episode on the first episode's order
         oa, ob = a.rollout(pol, alert_mask=True), b.rollout(pol, alert_mask=True)
-        for k in ("return", "alerts", "final_return", "alert_days", "return_snapshot"):
+        for k in ("alerts", "alert_days"):
             assert torch.equal(oa[k], ob[k]), k
+        for k in ("return", "final_return", "return_snapshot"):
+            torch.testing.assert_close(oa[k], ob[k], rtol=1e-6, atol=1e-5)
         a._order_stale = False
     sa, sb = a.state(), b.state()
     for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
+        if k == "episode_return":
+            torch.testing.assert_close(sa[k], sb[k], rtol=1e-6, atol=1e-5)
+        else:
+            assert torch.equal(sa[k], sb[k]), k
     a.close()
     b.close()
 

@@ -118,7 +118,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_rollout.restype = C.c_int
     lib.w2a_rollout.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.w2a_rollout_order_workspace_bytes.restype = C.c_size_t
-    lib.w2a_rollout_order_workspace_bytes.argtypes = [i64]
+    lib.w2a_rollout_order_workspace_bytes.argtypes = [i64, i64]
     lib.w2a_rollout_order.restype = C.c_int
     lib.w2a_rollout_order.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_policy_actions.restype = C.c_int

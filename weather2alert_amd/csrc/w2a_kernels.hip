@@ -52,8 +52,19 @@
   } while (0)
 
 // k_rollout is compiled per (policy kind, day bitmaps wanted, corrected-semantics flags set)
+#ifndef W2A_ROLLOUT_WIDE
+#define W2A_ROLLOUT_WIDE 1  // 1: lane = env day loop (k_rollout64) when a visiting order is set; 0: always 4 lanes per env
+#endif
 template <int KIND>
 static void launch_rollout_kind(bool masks, bool fixes, unsigned grid, hipStream_t s, const RolloutArgs &a) {
+  if (W2A_ROLLOUT_WIDE && a.order) {
+    const unsigned g64 = (unsigned)((((a.n + BLOCK - 1) / BLOCK) + 7) / 8 * 8);
+    if (masks && fixes) hipLaunchKernelGGL((k_rollout64<KIND, true, true>), dim3(g64), dim3(BLOCK), 0, s, a);
+    else if (masks) hipLaunchKernelGGL((k_rollout64<KIND, true, false>), dim3(g64), dim3(BLOCK), 0, s, a);
+    else if (fixes) hipLaunchKernelGGL((k_rollout64<KIND, false, true>), dim3(g64), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_rollout64<KIND, false, false>), dim3(g64), dim3(BLOCK), 0, s, a);
+    return;
+  }
   if (masks && fixes) hipLaunchKernelGGL((k_rollout<KIND, true, true>), dim3(grid), dim3(BLOCK), 0, s, a);
   else if (masks) hipLaunchKernelGGL((k_rollout<KIND, true, false>), dim3(grid), dim3(BLOCK), 0, s, a);
   else if (fixes) hipLaunchKernelGGL((k_rollout<KIND, false, true>), dim3(grid), dim3(BLOCK), 0, s, a);
@@ -427,28 +438,26 @@ int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
   return W2A_OK;
 }
 
-size_t w2a_rollout_order_workspace_bytes(int64_t num_envs) {
-  if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
-  return align256(4 * (size_t)num_envs) * 4 + align256(cub_group_bytes(num_envs));
+size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows) {
+  if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll) return 0;
+  return align256(4 * (size_t)num_envs) + align256(4 * (size_t)table_rows);
 }
 
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_order: NULL argument");
-  if (workspace_bytes < w2a_rollout_order_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace too small");
+  const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
+  if (workspace_bytes < w2a_rollout_order_workspace_bytes(env->n, rows)) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace must be 256-B aligned");
   const size_t n = (size_t)env->n;
   char *p = (char *)workspace;
   uint32_t *order = (uint32_t *)p; p += align256(4 * n);  // stays in use after the call
-  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
-  uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
-  uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
-  size_t cub_bytes = cub_group_bytes(env->n);
+  uint32_t *cnt = (uint32_t *)p;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rollout_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
+  HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)rows, s));
+  hipLaunchKernelGGL(k_order_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, cnt, env->n);
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, s, cnt, (int32_t)rows);
+  hipLaunchKernelGGL(k_order_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, cnt, order, env->n);
   HIP_TRY(hipGetLastError());
-  int bits = 1;
-  while ((1ll << bits) < (int64_t)env->tb.S_w * env->tb.Y) ++bits;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, order, (int)n, 0, bits, s));
   env->order = order;
   return W2A_OK;
 }

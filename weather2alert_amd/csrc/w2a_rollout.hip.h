@@ -34,11 +34,33 @@ struct RolloutArgs {
                                   // fabric traffic per 1 M-env episode, profiles/r02/rollout_counters.log)
 };
 
-__global__ void k_rollout_keys(const uint4 *cold, uint32_t *keys, uint32_t *idx, int64_t n) {
+// visiting order = counting sort of the env ids by feature row (cold.x = county_w * Y + year_i): histogram, scan,
+// scatter. The order inside a row is whatever the atomics give -- any permutation is correct, see above.
+__global__ void k_order_hist(const uint4 *cold, uint32_t *cnt, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = cold[i].x;  // feature row of the episode: county_w * Y + year_i
-  idx[i] = (uint32_t)i;
+  if (i < n) atomicAdd(&cnt[cold[i].x], 1u);
+}
+__global__ __launch_bounds__(1024) void k_order_scan(uint32_t *cnt, int32_t rows) {  // one workgroup, exclusive, in place
+  __shared__ uint32_t s_sum[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (rows + 1023) / 1024;
+  const int r0 = min(rows, tid * chunk), r1 = min(rows, r0 + chunk);
+  uint32_t mine = 0;
+  for (int r = r0; r < r1; ++r) mine += cnt[r];
+  s_sum[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = tid >= d ? s_sum[tid - d] : 0u;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[tid] - mine;
+  for (int r = r0; r < r1; ++r) { const uint32_t c = cnt[r]; cnt[r] = run; run += c; }
+}
+__global__ void k_order_scatter(const uint4 *cold, uint32_t *cursor, uint32_t *order, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) order[atomicAdd(&cursor[cold[i].x], 1u)] = (uint32_t)i;
 }
 
 // the built-in policies on what the reference's agent would see (shared by k_rollout and k_policy_actions)
@@ -181,6 +203,158 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const RolloutArgs a) {
       feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
   }
   if (valid && l == 0) {
+    store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
+                                  __float_as_uint(ret_total), (uint32_t)budget));
+    if (a.ret_out) a.ret_out[e] = ret;
+    if (a.alerts_out) a.alerts_out[e] = alerts;
+    if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
+    if (MASKS && a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+      a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+    if (MASKS && a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+      a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+    if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
+    if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// lane = env form of the day loop
+// ----------------------------------------------------------------------------------------
+// With the visiting order the envs of a wave share one or two feature rows, so a lane can afford to read its env's
+// whole row every day (64 lanes, one or two distinct lines per load instruction). One lane per env then removes what
+// the 4-lanes-per-env form pays per day: the cross-lane reductions and the state / policy arithmetic repeated on the
+// three other lanes. The coefficients stay in registers as f32 (the converts are redone every day, W2A_RO64_F32COEF = 1)
+// or as fp64 (twice the registers, half the converts).
+#ifndef W2A_RO64_F32COEF
+#define W2A_RO64_F32COEF 1
+#endif
+#define RO64_SLOTS 30  // slots 0..29 enter the logits (30 carries the gate flag with a zero coefficient, 31 is zero)
+
+template <int KIND, bool MASKS, bool FIXES>
+__global__ __launch_bounds__(BLOCK) void k_rollout64(const RolloutArgs a) {
+  const int64_t slot64 = (int64_t)logical_block(blockIdx.x, gridDim.x >> 3) * BLOCK + threadIdx.x;
+  if (slot64 - (threadIdx.x & 63) >= a.n) return;  // whole wave past the end
+  const bool valid = slot64 < a.n;
+  const uint32_t slot = (uint32_t)(valid ? slot64 : (a.n - 1));
+  const uint32_t e = a.order ? a.order[slot] : slot;  // the env this lane serves
+  uint4 c2, hot;
+  load_step_state(a.st, e, c2, hot);
+  const uint4 cold = load_cold(a.st, e);
+  uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
+  uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
+  const uint32_t ndays = D1_NDAYS(hot.y);
+  const int32_t budget = (int32_t)hot.w;
+  bool fin = D1_FIN(hot.y) != 0;
+  float ret_total = __uint_as_float(hot.z);
+  const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+  const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
+  // the env's two coefficient rows, once per launch
+#if W2A_RO64_F32COEF
+  float wb[32], we[32];
+#else
+  double wb[32], we[32];
+#endif
+  {
+    const float4 *wp = a.tb.W + (size_t)wrow * (2 * ROWF / 4);
+#pragma unroll
+    for (int q = 0; q < ROWF / 4; ++q) {
+      const float4 b = wp[q], f = wp[ROWF / 4 + q];
+      wb[4 * q] = b.x; wb[4 * q + 1] = b.y; wb[4 * q + 2] = b.z; wb[4 * q + 3] = b.w;
+      we[4 * q] = f.x; we[4 * q + 1] = f.y; we[4 * q + 2] = f.z; we[4 * q + 3] = f.w;
+    }
+  }
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+  float ret = 0.0f;
+  int32_t alerts = 0, over = 0;
+  uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
+  uint32_t att_word = 0, att_idx = 0xFFFFFFFFu;
+  float snap = 0.0f;
+  bool snapped = false;
+  float feat = 0.0f;
+  if (KIND == W2A_POLICY_THRESHOLD)
+    feat = Xf[((size_t)((a.pol.obs_lag && t > 0 ? t - 1 : t) * rows_per_day + cold.x)) * ROWF + a.pol_slot];
+  bool active = !fin && valid;
+  for (int s = 0; s < a.n_steps; ++s) {
+    if (!__any(active)) break;
+    const int32_t act = policy_action(KIND, a.pol, pstream, t, budget - (int32_t)used, feat);
+    // ---- env.py:242-250
+    const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
+    const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
+    const uint32_t used2 = used + actual;
+    const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+    const uint32_t day_row = t * rows_per_day + cold.x;
+    float xv[32];
+    {
+      const float4 *xp = a.tb.X + (size_t)day_row * (ROWF / 4);
+#pragma unroll
+      for (int q = 0; q < ROWF / 4; ++q) {
+        if (q == RT_QUAD) continue;  // slots 24..27 are run-time fields
+        const float4 v = xp[q];
+        xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+      }
+    }
+    const float today = (KIND == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    const uint32_t fx = FIXES ? a.tb.fixes : 0u;
+    const float f_a2w = (float)__popc(hist2);
+    xv[4 * RT_QUAD] = (t > 0) ? (float)((fx & W2A_FIX_LAG) ? last : actual) : 0.0f;
+    xv[4 * RT_QUAD + 1] = (float)streak;
+    xv[4 * RT_QUAD + 2] = (float)(budget - (int32_t)used2);
+    xv[4 * RT_QUAD + 3] = f_a2w;
+    if (FIXES && (fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k == a.tb.slot_hist2w) xv[k] = f_a2w;
+    }
+    double zb = 0.0, ze = 0.0;
+#pragma unroll
+    for (int k = 0; k < RO64_SLOTS; ++k) {
+#if W2A_RO64_F32COEF
+      asm volatile("" : "+v"(wb[k]), "+v"(we[k]));  // keep the coefficients f32: the converts are redone every day
+#endif
+      const double xk = (double)xv[k];
+      zb = fma(xk, (double)wb[k], zb);
+      ze = fma(xk, (double)we[k], ze);
+    }
+    if (!(xv[30] > 0.5f)) ze = -__builtin_inf();
+    float r = reward_from_logits(zb, ze, actual);
+    if ((fx & W2A_FIX_PENALTY) && act == 1 && atb_s) r = -1.0f;
+    if (active) {
+      const bool done = (t + 1 >= ndays);
+      ret += r;
+      ret_total += r;
+      alerts += (int32_t)actual;
+      over += (act == 1 && atb_s) ? 1 : 0;
+      if (MASKS && a.alert_mask && actual) {
+        const uint32_t wi = t >> 5;
+        if (wi != mask_idx) {
+          if (mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+            a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+          mask_idx = wi;
+          mask_word = 0;
+        }
+        mask_word |= 1u << (t & 31);
+      }
+      if (MASKS && a.attempt_mask && act == 1) {
+        const uint32_t wi = t >> 5;
+        if (wi != att_idx) {
+          if (att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+            a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+          att_idx = wi;
+          att_word = 0;
+        }
+        att_word |= 1u << (t & 31);
+      }
+      if (MASKS && (done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
+      used = used2; hist = hist2; last = actual; atb = atb_s;
+      if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
+      else { fin = true; active = false; }
+      feat = a.pol.obs_lag ? today : feat;
+    }
+    if (KIND == W2A_POLICY_THRESHOLD && !a.pol.obs_lag && active)
+      feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
+  }
+  if (valid) {
     store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
                                   __float_as_uint(ret_total), (uint32_t)budget));
     if (a.ret_out) a.ret_out[e] = ret;

@@ -620,7 +620,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         with torch.cuda.device(dev):
             if not self._pm and getattr(self, "_order_stale", True) and self.rollout_order:
                 if self._order_ws is None:
-                    self._order_ws = torch.empty(self._lib.w2a_rollout_order_workspace_bytes(n), dtype=torch.uint8, device=dev)
+                    self._order_ws = torch.empty(self._lib.w2a_rollout_order_workspace_bytes(n, ct.S_w * ct.Y), dtype=torch.uint8, device=dev)
                 _ffi.check(self._lib.w2a_rollout_order(self._h, self._order_ws.data_ptr(), self._order_ws.numel(),
                                                        self._stream()), "w2a_rollout_order")
                 self._order_stale = False
