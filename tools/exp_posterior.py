@@ -20,3 +20,12 @@ e0.record()
 for i in range(40): env.step(pool[i&7])
 e1.record(); torch.cuda.synchronize()
 print("pm us/step", e0.elapsed_time(e1)*1e3/40)
+# whole-episode policy rollout in this mode (policy kernel + reward kernels + step kernel per day, no observations)
+import time
+env.reset(seed=1)
+pol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
+env.rollout(pol)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+out = env.rollout(pol)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("pm rollout: %d envs x %d days in %.2f ms = %.2f G env-steps/s (%.1f us per day)" % (n, ct.T, dt * 1e3, n * ct.T / dt / 1e9, dt * 1e6 / ct.T))

@@ -672,8 +672,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
                        "w2a_policy_actions")
             _ffi.check(lib.w2a_posterior_mean_reward(h, act.data_ptr(), _ffi.ACT_I32, self._rew_ptr, stream),
                        "w2a_posterior_mean_reward")
-            _ffi.check(self._w2a_step(h, act.data_ptr(), _ffi.ACT_I32, self._obs_ptr, self._rew_ptr, self._done_ptr,
-                                      self._fr_ptr, self._step_flags, stream), "w2a_step")
+            # like k_rollout, no observation rows are written (the next step() or reset() brings them up to date)
+            _ffi.check(self._w2a_step(h, act.data_ptr(), _ffi.ACT_I32, None, self._rew_ptr, self._done_ptr,
+                                      self._fr_ptr, self._step_flags | _ffi.STEP_NO_OBS, stream), "w2a_step")
             out["return"] += self._reward
             if snap is not None and t0 + k + 1 == n_days - 2:  # the moment the reference's callbacks read the env
                 snap.copy_(self.state()["episode_return"])
