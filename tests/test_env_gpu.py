@@ -676,6 +676,33 @@ def test_corrected_semantics_flags(dev, fixes):
     ref.close()
 
 
+@pytest.mark.parametrize("order", [True, False])
+def test_rollout_with_corrected_semantics_flags(dev, order):
+    """rollout() on an env with fixes={'alert_2wks', 'lag', 'penalty'}: both day-loop kernels (lane = env with the
+    visiting order, 4 lanes per env without) against the oracle's policy loop on the same corrections."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    fixes = ("alert_2wks", "lag", "penalty")
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=6, seed=31)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, fixes=fixes)
+    n = 1500 + 11
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", fixes=fixes, rollout_order=order)
+    env.reset(seed=4, options={"budget": 5})
+    _oracle_for_env(env, V)
+    table = (np.random.default_rng(2).random((ct.T, 4)) < 0.35).astype(np.uint8)
+    pol = dict(kind="table", table=table)
+    out = env.rollout(pol, alert_mask=True)
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, pol, ct.T, None)
+    assert ov_o.sum() > 0  # alerts were attempted at budget: the penalty correction is exercised
+    np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
+    np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    assert out["done"].all() and env.check_status() == 0
+    env.close()
+
+
 def test_corrected_augmentation_and_budget(dev):
     from weather2alert_amd import HeatAlertVecEnv
 
