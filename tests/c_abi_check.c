@@ -22,6 +22,7 @@ int main(void) {
   if (w2a_step(NULL, NULL, W2A_ACT_I32, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 6;
   if (w2a_rollout(NULL, &p, 1, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL) != W2A_ERR_ARG) return 7;
   if (w2a_policy_actions(NULL, &p, NULL, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 10;
+  if (w2a_rollout_posterior_mean(NULL, &p, 1, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL) != W2A_ERR_ARG) return 13;
   if (w2a_set_semantics(NULL, W2A_FIX_ALL) != W2A_ERR_ARG) return 8;
   if (w2a_sort_workspace_bytes(0) != 0) return 9;
   if (w2a_rollout_order_workspace_bytes(0, 10) != 0 || w2a_rollout_order_workspace_bytes(1000, 10) < 4 * 1000) return 11;

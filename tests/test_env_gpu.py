@@ -982,9 +982,11 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
     sm.close()
 
 
-@pytest.mark.parametrize("kind", ["bernoulli", "threshold", "table"])
-def test_posterior_mean_rollout_matches_policy_loop(dev, kind):
-    """rollout() with reward_mode='posterior_mean' (policy kernel + reward kernels + step kernel per day) against the
+@pytest.mark.parametrize("kind,one_launch", [("bernoulli", True), ("threshold", True), ("table", True),
+                                             ("threshold", False), ("table", False)])
+def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch):
+    """rollout() with reward_mode='posterior_mean' -- the whole-episode kernel k_pm_rollout (one_launch) and the per-day
+    sequence policy kernel + reward kernels + step kernel that serves what it does not -- against the
     oracle's policy loop on the all-draws reward: alerts, over-budget attempts and alert days exact, returns to f32
     accumulation accuracy; a partial rollout, explicit steps in between, then the rest; and the next episode after the
     lock-step autoreset."""
@@ -996,6 +998,7 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind):
     n, gid0 = 700, 1000
     env = HeatAlertVecEnv(n, tables=ct, device=dev, env_gid0=gid0, similar_climate_counties=True,
                           reward_mode="posterior_mean")
+    env.pm_rollout_kernel = one_launch
     env.reset(seed=21, options={"budget": 7})
     st = _oracle_for_env(env, V)
     rng = np.random.default_rng(0)

@@ -13,7 +13,7 @@ ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE = 1, 2, 8, 16, 32
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 7
+ABI_VERSION = 8
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -21,7 +21,7 @@ BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
-    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order", "w2a_policy_actions", "w2a_set_semantics",
+    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
     "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
 ]
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
@@ -121,6 +121,8 @@ def load(build_if_missing: bool = True):
     lib.w2a_rollout_order_workspace_bytes.argtypes = [i64, i64]
     lib.w2a_rollout_order.restype = C.c_int
     lib.w2a_rollout_order.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.w2a_rollout_posterior_mean.restype = C.c_int
+    lib.w2a_rollout_posterior_mean.argtypes = [vp, C.POINTER(Policy), i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.w2a_policy_actions.restype = C.c_int
     lib.w2a_policy_actions.argtypes = [vp, C.POINTER(Policy), vp, vp, vp, vp, vp, i32, vp]
     if lib.w2a_abi_version() != ABI_VERSION:

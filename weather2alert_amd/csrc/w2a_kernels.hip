@@ -52,6 +52,22 @@
   } while (0)
 
 // k_rollout is compiled per (policy kind, day bitmaps wanted, corrected-semantics flags set)
+// k_pm_rollout per (policy kind, day bitmaps wanted)
+template <int KIND>
+static void launch_pm_rollout_kind(bool masks, unsigned grid, hipStream_t s, const PmRolloutArgs &a) {
+  if (masks) hipLaunchKernelGGL((k_pm_rollout<7, KIND, true>), dim3(grid), dim3(PMV_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((k_pm_rollout<7, KIND, false>), dim3(grid), dim3(PMV_THREADS), 0, s, a);
+}
+static void launch_pm_rollout(int kind, bool masks, unsigned grid, hipStream_t s, const PmRolloutArgs &a) {
+  switch (kind) {
+    case W2A_POLICY_ALWAYS: launch_pm_rollout_kind<W2A_POLICY_ALWAYS>(masks, grid, s, a); break;
+    case W2A_POLICY_BERNOULLI: launch_pm_rollout_kind<W2A_POLICY_BERNOULLI>(masks, grid, s, a); break;
+    case W2A_POLICY_THRESHOLD: launch_pm_rollout_kind<W2A_POLICY_THRESHOLD>(masks, grid, s, a); break;
+    case W2A_POLICY_TABLE: launch_pm_rollout_kind<W2A_POLICY_TABLE>(masks, grid, s, a); break;
+    default: launch_pm_rollout_kind<W2A_POLICY_NEVER>(masks, grid, s, a); break;
+  }
+}
+
 #ifndef W2A_ROLLOUT_WIDE
 #define W2A_ROLLOUT_WIDE 1  // 1: lane = env day loop (k_rollout64) when a visiting order is set; 0: always 4 lanes per env
 #endif
@@ -491,6 +507,45 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
+  HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out,
+                               int32_t *alerts_out, int32_t *attempts_over_budget, uint32_t *alert_mask,
+                               uint32_t *attempt_mask, int32_t mask_words, float *last_return, float *ret_snapshot,
+                               void *stream) {
+  if (!env || !policy) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: NULL argument");
+  if (n_steps <= 0) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: n_steps must be positive");
+  if (policy->kind < W2A_POLICY_NEVER || policy->kind > W2A_POLICY_TABLE) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: bad policy kind");
+  if (policy->kind == W2A_POLICY_TABLE && (!policy->table || policy->table_R <= 0))
+    return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: tabular policy needs table [T][table_R] and table_R > 0");
+  if ((alert_mask || attempt_mask) && mask_words * 32 < env->tb.T)
+    return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: alert_mask / attempt_mask need ceil(T/32) words per env");
+  if (!env->perm_valid)
+    return fail(W2A_ERR_STATE, "w2a_rollout_posterior_mean: call w2a_group_by_column after every reset");
+  if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: not available with corrected-semantics flags");
+  if (env->tb.n_samples > W2A_PMV_NPAD || env->w_tail_used || W2A_PM_MATRIX) return 1;  // not applicable: use the per-day calls
+  PmRolloutArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  RolloutArgs &a = pa.r;
+  a.tb = env->tb; a.st = env->st; a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
+  a.pol = *policy;
+  if (policy->kind == W2A_POLICY_THRESHOLD) {
+    if (policy->obs_col < 0 || policy->obs_col >= env->tb.n_obs) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: obs_col outside the observation");
+    int slot = env->obs_slot_host[policy->obs_col];
+    if (slot >= 24 && slot <= 27) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: threshold policies read table-sourced columns only");
+    a.pol_slot = slot;
+  }
+  a.n_steps = n_steps; a.ret_out = ret_out; a.alerts_out = alerts_out; a.attempts_over_budget = attempts_over_budget;
+  a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words; a.last_return = last_return;
+  a.ret_snapshot = ret_snapshot;
+  pa.perm = env->perm; pa.tiles = env->tiles; pa.n_tiles = env->n_tiles; pa.wd = env->wd;
+  hipStream_t s = (hipStream_t)stream;
+  if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
+  if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
+  const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
+  launch_pm_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, grid, s, pa);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
 }

@@ -370,6 +370,199 @@ __global__ __launch_bounds__(BLOCK) void k_rollout64(const RolloutArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------
+// whole-episode rollout with the posterior-mean reward: k_rollout64's day loop around k_posterior_mean_v's reward
+// ----------------------------------------------------------------------------------------
+// One workgroup = one tile of the posterior-mean kernel (<= PMV_THREADS envs of ONE coefficient column, lane = env).
+// The column's coefficient block is staged in LDS once per launch instead of once per day, the per-day pre-pass and
+// the separate step kernel disappear, state stays in registers. Per day: policy, budget gate, run-time fields, the
+// env's feature row, the baseline pass over all draws, the effectiveness phase shared by all waves (see
+// k_posterior_mean_v), reward, state update. Needs n_samples <= W2A_PMV_NPAD (the host loop of w2a_policy_actions +
+// w2a_posterior_mean_reward + w2a_step serves larger draw counts).
+struct PmRolloutArgs {
+  RolloutArgs r;
+  const uint32_t *perm;   // env ids sorted by coefficient column
+  const uint4 *tiles;
+  const uint32_t *n_tiles;
+  const double *wd;
+};
+
+template <int KS, int KIND, bool MASKS>
+__global__ __launch_bounds__(PMV_THREADS, 4) void k_pm_rollout(const PmRolloutArgs pa) {
+  const RolloutArgs &a = pa.r;
+  constexpr int WAVES = PMV_THREADS / 64;
+  __shared__ uint32_t s_wga[WAVES];
+  __shared__ double sW[W2A_PMV_NPAD][2][ROWF];
+  __shared__ float4 s_ax[64][KS];
+  __shared__ double s_part[WAVES][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15;
+  const uint32_t n_tiles = *pa.n_tiles, per_xcd = (n_tiles + 7u) >> 3;
+  const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles) return;
+  const uint4 tl = pa.tiles[tile];
+  const uint32_t col = __builtin_amdgcn_readfirstlane(tl.z);
+  const int rows = (int)__builtin_amdgcn_readfirstlane(tl.y);
+  const int n_samples = a.tb.n_samples;
+  const bool valid = tid < rows;
+  const uint32_t e = pa.perm[tl.x + (valid ? tid : 0)];
+  uint4 c2, hot;
+  load_step_state(a.st, e, c2, hot);
+  const uint4 cold = load_cold(a.st, e);
+  uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
+  uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
+  const uint32_t ndays = D1_NDAYS(hot.y);
+  const int32_t budget = (int32_t)hot.w;
+  bool fin = D1_FIN(hot.y) != 0;
+  float ret_total = __uint_as_float(hot.z);
+  const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+  // the column's coefficient block, once per launch
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(pa.wd + (size_t)col * n_samples * (2 * ROWF));
+    uint4 *dst = reinterpret_cast<uint4 *>(&sW[0][0][0]);
+    for (int idx = tid; idx < n_samples * (2 * ROWF / 2); idx += PMV_THREADS) dst[idx] = src[idx];
+  }
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+  float ret = 0.0f;
+  int32_t alerts = 0, over = 0;
+  uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
+  uint32_t att_word = 0, att_idx = 0xFFFFFFFFu;
+  float snap = 0.0f;
+  bool snapped = false;
+  float feat = 0.0f;
+  if (KIND == W2A_POLICY_THRESHOLD)
+    feat = Xf[((size_t)((a.pol.obs_lag && t > 0 ? t - 1 : t) * rows_per_day + cold.x)) * ROWF + a.pol_slot];
+  bool active = !fin && valid;
+  for (int s = 0; s < a.n_steps; ++s) {
+    if (!__syncthreads_or(active ? 1 : 0)) break;  // also: sW is staged, last day's LDS reads are done
+    const int32_t act = policy_action(KIND, a.pol, pstream, t, budget - (int32_t)used, feat);
+    // ---- env.py:242-250
+    const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
+    const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
+    const uint32_t used2 = used + actual;
+    const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+    const uint32_t day_row = t * rows_per_day + cold.x;
+    float4 xf[KS];
+    {
+      const float4 *xp = a.tb.X + (size_t)day_row * (ROWF / 4);
+#pragma unroll
+      for (int q = 0; q < KS; ++q) xf[q] = xp[q];
+      xf[RT_QUAD] = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak, (float)(budget - (int32_t)used2),
+                                (float)__popc(hist2));
+    }
+    const float today = (KIND == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    // effectiveness enters through eff * gate * actual (env.py:218-221); inactive rows take no part
+    const uint32_t ga = (active && actual && Xf[(size_t)day_row * ROWF + 30] > 0.5f) ? 1u : 0u;
+    const uint64_t bal = __ballot(ga != 0);
+    if (lane == 0) s_wga[wave] = (uint32_t)__popcll(bal);
+    double contrib = 0.0;
+    if (64 * wave < rows) {  // baseline pass: the wave's own rows, every draw
+      double ax[4 * KS];
+      pmv_widen<KS>(xf, ax);
+      contrib = pmv_draws<KS>(sW, n_samples, l15, ax);
+    }
+    __syncthreads();
+    uint32_t G = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    int n_eff = 0;
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = s_wga[w];
+      G += w < wave ? c : 0u;
+      n_eff += (int)c;
+    }
+    n_eff = __builtin_amdgcn_readfirstlane(n_eff);
+    for (int grp = 0; grp < n_eff; grp += 64) {  // effectiveness phase, as in k_posterior_mean_v
+      const int cnt = min(64, n_eff - grp);
+      const int j_own = (int)G - grp;
+      const bool own = ga && j_own >= 0 && j_own < 64;
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) s_ax[j_own][q] = xf[q];
+      }
+      __syncthreads();
+      const int R = (cnt + 15) >> 4, P = R == 1 ? 4 : (R == 2 ? 2 : 1);
+      const int drow = lane >> 4;
+      const int j = l15 + 16 * (drow % R);
+      const int sub = drow / R;
+      const int d0 = wave * n_samples / WAVES, d1 = (wave + 1) * n_samples / WAVES;
+      double part = 0.0;
+      {
+        float4 ef[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) ef[q] = s_ax[j < cnt ? j : 0][q];
+        double ax[4 * KS];
+        pmv_widen<KS>(ef, ax);
+#pragma unroll 1
+        for (int dd = d0; dd < d1; dd += P) {
+          const int sl = dd + sub;
+          const float tt = pmv_term<KS, true>(sW, sl < d1 ? sl : d1 - 1, l15, ax);
+          part += (sl < d1 && sub < P) ? (double)tt : 0.0;
+        }
+      }
+      s_part[wave][lane] = part;
+      __syncthreads();
+      if (own) {
+        double tsum = 0.0;
+#pragma unroll 1
+        for (int w = 0; w < WAVES; ++w)
+#pragma unroll 1
+          for (int p = 0; p < P; ++p) tsum += s_part[w][(j_own & 15) + 16 * ((j_own >> 4) + R * p)];
+        contrib = tsum;
+      }
+    }
+    const float r = (float)(-(1000.0 / 152.0) * contrib / (double)n_samples);
+    if (active) {
+      const bool done = (t + 1 >= ndays);
+      ret += r;
+      ret_total += r;
+      alerts += (int32_t)actual;
+      over += (act == 1 && atb_s) ? 1 : 0;
+      if (MASKS && a.alert_mask && actual) {
+        const uint32_t wi = t >> 5;
+        if (wi != mask_idx) {
+          if (mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+            a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+          mask_idx = wi;
+          mask_word = 0;
+        }
+        mask_word |= 1u << (t & 31);
+      }
+      if (MASKS && a.attempt_mask && act == 1) {
+        const uint32_t wi = t >> 5;
+        if (wi != att_idx) {
+          if (att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+            a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+          att_idx = wi;
+          att_word = 0;
+        }
+        att_word |= 1u << (t & 31);
+      }
+      if (MASKS && (done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
+      used = used2; hist = hist2; last = actual; atb = atb_s;
+      if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
+      else { fin = true; active = false; }
+      feat = a.pol.obs_lag ? today : feat;
+    }
+    if (KIND == W2A_POLICY_THRESHOLD && !a.pol.obs_lag && active)
+      feat = Xf[(size_t)(t * rows_per_day + cold.x) * ROWF + a.pol_slot];
+  }
+  if (valid) {
+    store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
+                                  __float_as_uint(ret_total), (uint32_t)budget));
+    if (a.ret_out) a.ret_out[e] = ret;
+    if (a.alerts_out) a.alerts_out[e] = alerts;
+    if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
+    if (MASKS && a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+      a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+    if (MASKS && a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+      a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+    if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
+    if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // one day of a built-in policy: the action of every env from its pre-step state (for policy loops whose step is
 // not k_rollout's: reward_mode = "posterior_mean")
 // ----------------------------------------------------------------------------------------

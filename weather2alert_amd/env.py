@@ -160,6 +160,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
             raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
         self.rollout_order = bool(rollout_order)  # rollout() visits the envs in feature-row order (speed only; A/B)
+        self.pm_rollout_kernel = True  # posterior_mean rollouts in one launch when possible (False: per-day launches)
         self._order_stale = True
         if episode_order not in ("iid", "sorted"):
             raise ValueError(f"episode_order {episode_order!r}")
@@ -662,8 +663,18 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 m.zero_()
         t0, n_days, fin = int(st0["t"][0]), int(st0["n_days"][0]), bool(st0["finished"][0])
         steps = 0 if fin else min(steps, n_days - t0)
-        act = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         lib, h, stream = self._lib, self._h, self._stream()
+        if steps and self.pm_rollout_kernel:  # the whole rollout in one launch, when the kernel applies
+            rc = lib.w2a_rollout_posterior_mean(h, C.byref(p), steps, out["return"].data_ptr(), out["alerts"].data_ptr(),
+                                                out["attempts_over_budget"].data_ptr(),
+                                                None if mask is None else mask.data_ptr(),
+                                                None if amask is None else amask.data_ptr(), words, self._fr_ptr,
+                                                None if snap is None else snap.data_ptr(), stream)
+            if rc == 0:
+                return steps
+            if rc != 1:
+                _ffi.check(rc, "w2a_rollout_posterior_mean")
+        act = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         for k in range(steps):
             _ffi.check(lib.w2a_policy_actions(h, C.byref(p), act.data_ptr(), out["alerts"].data_ptr(),
                                               out["attempts_over_budget"].data_ptr(),
