@@ -103,7 +103,7 @@ def main():
         collect(tag, out, a.round)
     logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
             "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log", "pm_trace.log",
-            "pm_variants.log", "pm_tests_matrix.log", "mfma_overlap_probe.log"]
+            "pm_variants.log", "pm_tests_matrix.log", "pm_rollout.log", "mfma_overlap_probe.log"]
     for f in logs:
         src = os.path.join(GO, f)
         if os.path.exists(src):
