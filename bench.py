@@ -83,6 +83,10 @@ def parse(argv=None):
     p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
                    help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
     p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
+    p.add_argument("--launch-timeout", type=float, default=1500.0,
+                   help="--gpus N self-launcher: seconds after which still-running ranks are terminated")
+    p.add_argument("--fail-rank", type=int, default=-1,
+                   help="(launcher test hook) this rank exits with code 3 right after start-up")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the multi-rank path (ranks share the GPUs there are; with the "
                         "launcher_stub workload it needs no GPU at all)")
@@ -105,28 +109,68 @@ def _free_port() -> int:
 
 def self_launch(args) -> int:
     """`--gpus N` without a launcher: one child per GPU. This process has not imported torch and never touches a
-    GPU; children are fresh interpreters (fork + exec of python), each of which initialises its own device."""
+    GPU; children are fresh interpreters (fork + exec of python), each of which initialises its own device.
+    All children are polled: when one exits non-zero (or the deadline passes) the others are terminated and the
+    failing rank's stderr tail is printed, so a rank that dies at start-up cannot leave the rest -- and the caller --
+    waiting in a rendezvous."""
     import subprocess
+    import tempfile
 
     n = args.gpus
     port = _free_port()
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        err = tempfile.TemporaryFile(mode="w+")
+        logs.append((out, err))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out, stderr=err, text=True))
+    deadline = time.time() + args.launch_timeout
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0], codes[bad[0]]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed, rc = next(r for r, c in enumerate(codes) if c is None), 124
+            print(f"bench.py: --launch-timeout {args.launch_timeout:.0f} s passed, rank {failed} still running",
+                  file=sys.stderr, flush=True)
+            break
+        time.sleep(0.05)
+    if failed is not None:  # children are plain child processes of ours: ending them is safe
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 5
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        logs[failed][1].seek(0)
+        tail = logs[failed][1].read()[-2000:]
+        print(f"bench.py: rank {failed} exited with code {rc}; the other ranks were terminated. Its stderr tail:\n{tail}",
+              file=sys.stderr, flush=True)
+        return rc if rc else 1
+    for r, (_, err) in enumerate(logs):  # forward what the ranks wrote to stderr (warnings), rank by rank
+        err.seek(0)
+        txt = err.read()
+        if txt:
+            sys.stderr.write(txt)
+    logs[0][0].seek(0)
+    line = [ln for ln in logs[0][0].read().splitlines() if ln.startswith("{")]
     if line:
         print(line[-1], flush=True)
-    elif rc == 0:
-        rc = 1
-    return rc
+        return 0
+    print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+    return 1
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -160,7 +204,9 @@ def cpu_baseline_multicore(wname, seed, procs, timeout=180):
     multiprocessing start-method pitfalls), each stepping its own share; aggregate = total / slowest."""
     import subprocess
 
-    n, steps = 65536, 154  # ~3-5 s per worker
+    # per-worker sample capped so that the leg stays short however many cores the host has (every worker also builds
+    # its own tables, ~10 s, outside its timed region)
+    n, steps = (65536, 154) if procs <= 32 else (16384, 154)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
                             json.dumps([wname, seed, n, steps, r])], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
@@ -177,8 +223,49 @@ def cpu_baseline_multicore(wname, seed, procs, timeout=180):
         raise RuntimeError(f"{procs - len(res)} of {procs} CPU workers failed or timed out")
     total = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)
-    return {"value": total / slowest, "cores": procs,
-            "sample": f"{procs} processes x {n} envs x {steps - 1} steps, slowest worker {slowest:.1f} s"}
+    return {"value": total / slowest, "unit": "env-steps/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} single-threaded processes (one per host core) x {n} envs x {steps - 1} steps of the "
+                      f"NumPy vector oracle, slowest worker {slowest:.1f} s"}
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cpus() -> dict:
+    """How many host CPUs this process may actually run on: the smaller of os.cpu_count(), the scheduler affinity mask
+    and the cgroup CPU quota (cpu.max, v2; cfs_quota_us / cfs_period_us, v1). A container that shows 256 CPUs but is
+    throttled to a 16-CPU quota can keep 16 single-threaded workers busy, not 256."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = info["os_cpu_count"]
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_quota_cpus"] = quota
+    usable = min(info["os_cpu_count"], info["affinity"])
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    info["usable"] = usable
+    return info
 
 
 def cpu_baseline(sd, ct, seed=0):
@@ -224,7 +311,7 @@ def cpu_baseline(sd, ct, seed=0):
         "sample": f"NumPy float64 vector oracle, {episodes} episodes of {n} envs x {steps - 1} steps of the same tables "
                   f"({dt:.1f} s)",
         "scalar_port_env_steps_per_s": scalar,
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
         "reference_env_steps_per_s_build_container": 646.0,  # BASELINE.md §2 (pandas env, 1 core; it cannot travel)
     }
 
@@ -291,6 +378,136 @@ def timed_steps(env, pool, steps, torch):
     return e0.elapsed_time(e1), time.perf_counter() - t0
 
 
+def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T):
+    """Reported extras of the single-GPU run, each measured in the same process after the headline; a failure in one of
+    them is recorded under its key and never loses the headline JSON line."""
+
+    def guarded(key, fn):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)}
+            torch.cuda.synchronize()
+
+    def always_alert():
+        # policy-pessimistic case: every env alerts every day with budget 153, so both coefficient rows are fetched on
+        # every env-step (the headline policy fetches the second one on ~6 %)
+        e2 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                             write_obs=not args.no_obs, budget=T, step_kernel=args.step_kernel)
+        e2.reset(seed=args.seed)
+        ones = [torch.ones(n, dtype=torch.int32, device=device)] * 16
+        timed_steps(e2, ones, 10, torch)
+        kms, _ = timed_steps(e2, ones, 130, torch)
+        us = kms * 1e3 / 130
+        out["always_alert_policy"] = {
+            "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
+            "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "budget=153 and action=1 every day: both 128-B coefficient rows are gathered on every "
+                    "env-step (worst case for the policy-dependent effectiveness-row skip)"}
+        e2.close()
+
+    def sorted_order():
+        e3 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                             write_obs=not args.no_obs, episode_order="sorted", step_kernel=args.step_kernel)
+        e3.reset(seed=args.seed)
+        timed_steps(e3, pool, 10, torch)
+        kms, _ = timed_steps(e3, pool, 130, torch)
+        us = kms * 1e3 / 130
+        out["sorted_episode_order"] = {
+            "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
+            "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
+                    "row after each reset"}
+        e3.close()
+
+    def posterior_mean():
+        # reward_mode="posterior_mean": the reward of every env-step as the mean over all 100 posterior draws (the dense
+        # "nn_full_medicare reward GEMM" of BASELINE configs[3]/[4]). Every kernel of the library in the same run:
+        # the vector-ALU form and the matrix-core (MFMA) forms, selected at run time; "auto" keeps the faster one.
+        flop_base = 2.0 * 28 * ct.n_samples * n  # baseline head: 28 coefficients x draws, multiply-add
+        res = {"unit": "env-steps/s (pre-pass + reward kernel + k_step64<given>)", "kernels": {}}
+        from weather2alert_amd import _ffi
+
+        for name in _ffi.PM_KERNELS:
+            e4 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                                 write_obs=not args.no_obs, reward_mode="posterior_mean", pm_kernel=name)
+            e4.reset(seed=args.seed)
+            timed_steps(e4, pool, 5, torch)
+            kms, _ = timed_steps(e4, pool, 40, torch)
+            us = kms * 1e3 / 40
+            # the reward kernel alone (HIP events around the C-ABI call; includes its 17-us pre-pass)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                _ffi.check(e4._lib.w2a_posterior_mean_reward(e4._h, pool[0].data_ptr(), _ffi.ACT_I32, e4._rew_ptr,
+                                                             e4._stream()), "w2a_posterior_mean_reward")
+            e1.record()
+            torch.cuda.synchronize()
+            res["kernels"][name] = {"us_per_step": us, "value": n / us * 1e6,
+                                    "reward_kernels_us": e0.elapsed_time(e1) * 1e3 / 10,
+                                    "tflops_baseline_head": flop_base / (us * 1e-6) / 1e12}
+            e4.close()
+        ea = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                             write_obs=not args.no_obs, reward_mode="posterior_mean", pm_kernel="auto")
+        ea.reset(seed=args.seed)
+        res["auto_choice"] = ea.pm_kernel_choice
+        res["auto_timing_us"] = ea.pm_kernel_timing_us
+        ea.close()
+        best = min(res["kernels"], key=lambda k: res["kernels"][k]["us_per_step"])
+        res.update(us_per_step=res["kernels"][best]["us_per_step"], value=res["kernels"][best]["value"], fastest=best,
+                   vector_peak_tflops_fp64=78.6,
+                   mfma_counters="profiles/r03/pm_counters_*.json (SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES per kernel)",
+                   note="per step: [envs of a column x 28 slots + bias] x [draws], sigmoid / gate / mean epilogue; the "
+                        "effectiveness head only for rows with an open-gate alert; time includes the pre-pass and the "
+                        "step kernel that consumes the reward")
+        out["posterior_mean_reward"] = res
+
+    def rollout():
+        e6 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment)
+        e6.reset(seed=args.seed)
+        rpol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
+        e6.rollout(rpol)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e6.rollout(rpol)
+        torch.cuda.synchronize()
+        dt_r = (time.perf_counter() - t0) / 5
+        out["on_device_rollout"] = {
+            "ms_per_episode": dt_r * 1e3, "value": n * ct.T / dt_r, "unit": "env-steps/s",
+            "note": "threshold policy evaluated in the kernel, 153 days per launch, envs visited in feature-row "
+                    "order (w2a_rollout_order, sort included), no observations written"}
+        e6.close()
+
+    def configs4():
+        # the single-GPU rate of the multi-GPU default workload (configs[4] = nn_full_medicare_all shape), so that
+        # `--gpus N` values have their own N = 1 denominator in this file
+        w4, n4, aug4, _ = WORKLOADS["configs4"]
+        sd4 = synth.make_synth(w4, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
+                               extra_confounder_fips=60)
+        e5 = HeatAlertVecEnv(n4, tables=tables.compile_from_synth(sd4), device=device,
+                             similar_climate_counties=aug4, write_obs=not args.no_obs)
+        e5.reset(seed=args.seed)
+        g4 = torch.Generator(device=device).manual_seed(4321)
+        pool4 = pool if n4 == n else [(torch.rand(n4, device=device, generator=g4) < 0.1).to(torch.int32)
+                                      for _ in range(16)]
+        timed_steps(e5, pool4, 10, torch)
+        kms, kwall = timed_steps(e5, pool4, 130, torch)
+        out["configs4_single_gpu"] = {
+            "kernel_us": kms * 1e3 / 130, "value": n4 * 130 / kwall, "unit": "env-steps/s",
+            "roofline_frac": cb["total"] * n4 / (kms * 1e-3 / 130) / 1e9 / HBM_PEAK_GBS,
+            "note": "python bench.py --gpus N (N > 1) runs this workload per GPU: compare its values with "
+                    "N x this one, not with the configs[2] headline above"}
+        e5.close()
+
+    guarded("always_alert_policy", always_alert)
+    guarded("sorted_episode_order", sorted_order)
+    guarded("posterior_mean_reward", posterior_mean)
+    guarded("on_device_rollout", rollout)
+    if args.workload == "configs2":
+        guarded("configs4_single_gpu", configs4)
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
         print(json.dumps(_cpu_worker(tuple(json.loads(sys.argv[2])))))
@@ -303,6 +520,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("W2A_BENCH_TEST_HANG_RANK") == str(rank):  # launcher test hook: a rank that never finishes
+        time.sleep(600)
+    if rank == args.fail_rank:
+        print(f"rank {rank}: --fail-rank test hook, exiting 3", file=sys.stderr, flush=True)
+        return 3
     if args.workload == "launcher_stub":
         return run_stub(args, rank, world)
 
@@ -499,92 +721,19 @@ def main():
         }
         if world == 1 and args.episode_order == "iid" and not args.graph and not args.no_extras:
             env.close()
-            # (1) policy-pessimistic case in the same run: every env alerts every day with budget 153, so both
-            # coefficient rows are fetched on every env-step (the headline policy fetches the second one on ~6 %)
-            e2 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
-                                 write_obs=not args.no_obs, budget=T, step_kernel=args.step_kernel)
-            e2.reset(seed=args.seed)
-            ones = [torch.ones(n, dtype=torch.int32, device=device)] * 16
-            timed_steps(e2, ones, 10, torch)
-            kms, _ = timed_steps(e2, ones, 130, torch)
-            us = kms * 1e3 / 130
-            out["always_alert_policy"] = {
-                "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
-                "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "budget=153 and action=1 every day: both 128-B coefficient rows are gathered on every "
-                        "env-step (worst case for the policy-dependent effectiveness-row skip)"}
-            e2.close()
-            # (2) the opt-in relabelled episode order, same workload
-            e3 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
-                                 write_obs=not args.no_obs, episode_order="sorted", step_kernel=args.step_kernel)
-            e3.reset(seed=args.seed)
-            timed_steps(e3, pool, 10, torch)
-            kms, _ = timed_steps(e3, pool, 130, torch)
-            us = kms * 1e3 / 130
-            out["sorted_episode_order"] = {
-                "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
-                "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
-                        "row after each reset"}
-            e3.close()
-            # (3) reward_mode="posterior_mean": the reward of every env-step as the mean over all 100 posterior draws
-            # (the dense "nn_full_medicare reward GEMM" of BASELINE configs[3]/[4]): fp64 FMAs on the vector ALU with
-            # DPP-broadcast coefficients (the fp64 MFMA form is an A/B build)
-            e4 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
-                                 write_obs=not args.no_obs, reward_mode="posterior_mean")
-            e4.reset(seed=args.seed)
-            timed_steps(e4, pool, 5, torch)
-            kms, _ = timed_steps(e4, pool, 40, torch)
-            us = kms * 1e3 / 40
-            flop_base = 2.0 * 28 * ct.n_samples * n              # baseline head: 28 coefficients x draws, multiply-add
-            out["posterior_mean_reward"] = {
-                "us_per_step": us, "value": n / us * 1e6,
-                "unit": "env-steps/s (k_pm_prep + k_posterior_mean_v + k_step64<given>)",
-                "tflops_fp64_baseline_head": flop_base / (us * 1e-6) / 1e12,
-                "vector_peak_tflops_fp64": 78.6,
-                "note": "per step: [envs of a column x 28 slots + bias] x [draws], lane = env, v_fmac_f64_dpp row_newbcast, "
-                        "f32 sigmoid / gate / mean; the effectiveness head only for rows with an open-gate alert; time "
-                        "includes the pre-pass and the step kernel that consumes the reward"}
-            e4.close()
-            # (3b) on-device policy rollout: one launch = one whole episode for every env
-            e6 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment)
-            e6.reset(seed=args.seed)
-            rpol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
-            e6.rollout(rpol)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                e6.rollout(rpol)
-            torch.cuda.synchronize()
-            dt_r = (time.perf_counter() - t0) / 5
-            out["on_device_rollout"] = {
-                "ms_per_episode": dt_r * 1e3, "value": n * ct.T / dt_r, "unit": "env-steps/s",
-                "note": "threshold policy evaluated in the kernel, 153 days per launch, envs visited in feature-row "
-                        "order (w2a_rollout_order, sort included), no observations written"}
-            e6.close()
-            # (4) the single-GPU rate of the multi-GPU default workload (configs[4] = nn_full_medicare_all shape), so
-            # that `--gpus N` values have their own N = 1 denominator in this file
-            if args.workload == "configs2":
-                w4, n4, aug4, _ = WORKLOADS["configs4"]
-                sd4 = synth.make_synth(w4, years=list(range(2006, 2017)), n_samples=100, seed=args.seed,
-                                       extra_confounder_fips=60)
-                e5 = HeatAlertVecEnv(n4, tables=tables.compile_from_synth(sd4), device=device,
-                                     similar_climate_counties=aug4, write_obs=not args.no_obs)
-                e5.reset(seed=args.seed)
-                timed_steps(e5, pool, 10, torch)
-                kms, kwall = timed_steps(e5, pool, 130, torch)
-                out["configs4_single_gpu"] = {
-                    "kernel_us": kms * 1e3 / 130, "value": n4 * 130 / kwall, "unit": "env-steps/s",
-                    "note": "python bench.py --gpus N (N > 1) runs this workload per GPU: compare its values with "
-                            "N x this one, not with the configs[2] headline above"}
-                e5.close()
+            extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
-            procs = min(16, os.cpu_count() or 1)
             try:
-                out["cpu_baseline"]["multi_core"] = cpu_baseline_multicore(wname, args.seed, procs)
-            except Exception as e:  # noqa: BLE001  (a reported extra, never fatal)
-                out["cpu_baseline"]["multi_core"] = {"error": repr(e)}
+                out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)
+                # all host cores this process may use, one single-threaded process per core
+                cpus = usable_cpus()
+                out["cpu_baseline"]["cpus"] = cpus
+                try:
+                    out["cpu_baseline"]["multi_core"] = cpu_baseline_multicore(wname, args.seed, cpus["usable"])
+                except Exception as e:  # noqa: BLE001  (a reported extra, never fatal)
+                    out["cpu_baseline"]["multi_core"] = {"error": repr(e)}
+            except Exception as e:  # noqa: BLE001  (the headline JSON line must survive a failing baseline leg)
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     env.close()
     wdist.barrier()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 8
+#define W2A_ABI_VERSION 9
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -56,6 +56,9 @@ enum {
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
   W2A_STEP_WIDE = 32,     /* force the 64-envs-per-wave kernel for small batches too (by default it serves batches of
                              >= 131 072 envs, the 4-lanes-per-env kernel smaller ones: the faster one on MI355X) */
+  W2A_STEP_SKIP_FINISHED = 64, /* with W2A_STEP_REWARD_GIVEN: envs whose episode is over are left untouched (reward
+                             written as 0, done 1, state / return / observation unchanged, no status bit): policy
+                             loops over batches that are not in lock step */
   W2A_STEP_REWARD_GIVEN = 16 /* `reward` is an INPUT: it already holds today's reward of every env
                              (w2a_posterior_mean_reward on the same state and actions); the step does everything
                              else of env.py:238-262 and accumulates that reward into the episode return */
@@ -174,7 +177,9 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
  * env.py:197-226): the reward of every env is the mean over ALL posterior draws of its coefficient column
  * instead of the one draw of the episode. One grouped fp64 contraction per step: per column
  * [envs x 32 slots] * [32 slots x 2 heads x n_samples draws], sigmoid / gate / mean epilogue.
- *   w2a_group_by_column        after EVERY reset: sorts the env ids by coefficient column into `workspace`
+ *   w2a_group_by_column        after EVERY reset -- and after anything else that changes which episode an env index
+ *                              holds: w2a_sort_episodes, a w2a_step with W2A_STEP_AUTORESET (both mark the grouping
+ *                              stale, and w2a_posterior_mean_reward then refuses to run) --: sorts the env ids by coefficient column into `workspace`
  *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples), 256-B aligned, must
  *                              stay alive while w2a_posterior_mean_reward is used) and writes a pre-scaled fp64 copy
  *                              of W there. W rows that give slot 28, 30 or 31 a coefficient are honoured (w2a_create
@@ -182,6 +187,14 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
  *   w2a_posterior_mean_reward  before w2a_step(..., W2A_STEP_REWARD_GIVEN) with the SAME actions: writes
  *                              reward [num_envs] f32 from the pre-step state. Same budget gate as the step
  *                              (env.py:242-246): an alert attempted at budget counts as no alert. */
+/*   w2a_set_posterior_kernel   which kernel computes the contraction (same results to ~1e-7; speed differs):
+ *                              W2A_PM_VECTOR (default) fp64 FMAs on the vector ALU with DPP-broadcast coefficients,
+ *                              W2A_PM_MATRIX_F64 the fp64 matrix-core form (v_mfma_f64_16x16x4_f64). On MI355X the fp64
+ *                              matrix rate equals the fp64 vector rate, so the vector form is the faster one; the
+ *                              choice also decides whether w2a_rollout_posterior_mean's one-launch kernel applies
+ *                              (it is built on the vector form). */
+enum { W2A_PM_VECTOR = 0, W2A_PM_MATRIX_F64 = 1 };
+int w2a_set_posterior_kernel(w2a_env *env, int kernel);
 size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples);
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream);

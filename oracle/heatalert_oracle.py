@@ -497,6 +497,27 @@ def devrng_policy_uniform(policy_seed: int, env_gid: int, episode_no: int, day: 
     return float(np.float32(u) * np.float32(2.3283064365386963e-10))
 
 
+def _mix64_np(z):
+    """_mix64 on uint64 arrays (wrap-around arithmetic)."""
+    z = z ^ (z >> np.uint64(30))
+    z = z * np.uint64(0xBF58476D1CE4E5B9)
+    z = z ^ (z >> np.uint64(27))
+    z = z * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def devrng_policy_uniform_vec(policy_seed: int, env_gid, episode_no, day) -> np.ndarray:
+    """devrng_policy_uniform for arrays of (env id, episode number, day): float32 uniforms in [0, 1)."""
+    with np.errstate(over="ignore"):
+        gid = np.asarray(env_gid, np.uint64)
+        ep = np.asarray(episode_no, np.uint64)
+        seed = np.uint64((policy_seed ^ 0xA5A5A5A55A5A5A5A) & _M64)
+        h = _mix64_np(seed + np.uint64(0x9E3779B97F4A7C15) * (gid + np.uint64(1)))
+        st = _mix64_np(h ^ (ep * np.uint64(0xBF58476D1CE4E5B9) + np.uint64(0x94D049BB133111EB)))
+        u = _mix64_np(st + (np.asarray(day, np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+    return u.astype(np.float32) * np.float32(2.3283064365386963e-10)
+
+
 def devrng_reset_tuple(seed, env_gid, episode_no, S, n_years, n_samples, fips_to_weather, sim_ptr, sim_cnt,
                        augment, default_budget_fn, sticky_budget, budget_kw, sample_mode):
     """Episode tuple the device reset kernel must produce for one env.
@@ -697,7 +718,10 @@ def _policy_actions(V, policy, seed_stream):
     elif kind == "always":
         act = np.ones(n, np.int64)
     elif kind == "bernoulli":
-        u = np.asarray([seed_stream(i, int(V.t[i])) for i in range(n)])
+        if hasattr(seed_stream, "vec"):  # vectorised form: seed_stream.vec(day array) -> uniforms of every env
+            u = np.asarray(seed_stream.vec(V.t))
+        else:
+            u = np.asarray([seed_stream(i, int(V.t[i])) for i in range(n)])
         act = (u.astype(np.float32) < np.float32(policy["p"])).astype(np.int64)
     elif kind == "threshold":
         tt = np.where((V.t > 0) & (policy.get("lag", 1) == 1), V.t - 1, V.t)

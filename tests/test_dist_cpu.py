@@ -112,6 +112,34 @@ def test_bench_launches_itself_for_several_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
+def test_bench_launcher_eight_ranks_and_a_rank_that_dies_at_startup():
+    """`--gpus 8` rehearsal on gloo (the stub workload: everything around the env -- process group, barrier, the
+    per-episode return all-gather, max-over-ranks timing, one JSON line) and failure propagation: a rank that exits at
+    start-up must end the whole launch within seconds with a non-zero code, not leave the others in the rendezvous."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--workload",
+            "launcher_stub", "--steps", "306", "--warmup", "0", "--num-envs", "1024"]
+    r = subprocess.run(base, capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["rccl_ranks_seen"] == 8 and out["gather_ok"]
+    assert out["config"]["num_envs_per_gpu"] == 1024 and out["collective_ms"] is not None
+    t0 = time.time()
+    bad = subprocess.run(base + ["--fail-rank", "5"], capture_output=True, text=True, env=env, timeout=120)
+    assert bad.returncode == 3 and time.time() - t0 < 60, (bad.returncode, time.time() - t0, bad.stderr[-1500:])
+    assert "rank 5 exited with code 3" in bad.stderr and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    # a launch that outlives --launch-timeout is ended too (rank 3 sleeps in place of working)
+    slow = subprocess.run(base + ["--fail-rank", "-2", "--launch-timeout", "4"], capture_output=True, text=True,
+                          env=dict(env, W2A_BENCH_TEST_HANG_RANK="3"), timeout=120)
+    assert slow.returncode == 124 and "launch-timeout" in slow.stderr
+
+
 def test_bench_defaults_follow_baseline_configs():
     import importlib.util
 

@@ -928,9 +928,11 @@ def test_other_schema_parity(dev):
     (3000 + 5, 48, 12, True, False, False), (37, 30, 100, False, False, False), (4096, 746, 100, True, False, False),
     (2048 + 9, 40, 20, True, True, False), (1500 + 3, 48, 12, True, False, True),
     (1500 + 7, 3, 130, False, False, False)])
-def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial, tail):
+@pytest.mark.parametrize("pm_kernel", ["vector", "matrix"])
+def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial, tail, pm_kernel):
     """reward_mode='posterior_mean' (legacy eval mode, _deprecated/env.py:332-342, on today's reward form): the
-    grouped fp64-MFMA GEMM + sigmoid/mean epilogue against the oracle's mean over every posterior draw; everything
+    grouped contraction + sigmoid/mean epilogue -- BOTH kernels of the one library, selected at run time: the
+    vector-ALU form (v_fmac_f64_dpp) and the matrix-core form (v_mfma_f64_16x16x4_f64) -- against the oracle's mean over every posterior draw; everything
     but the reward (observations, integer state, termination) equals the sampled-reward env. Ragged draw counts
     (12: a partial 16-column MFMA tile), tiles that span many coefficient columns (n = 37), the full 746-column
     table, augmentation (Q8: the coefficient column differs from the weather county), and 3 columns x 130 draws: column
@@ -951,7 +953,9 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
     V = O.VectorOracle(rd, sd.fips_weather, sd.years, reward_mode="posterior_mean")
     rng = np.random.default_rng(n)
     ep = _random_tuples(ct, n, rng, augment)
-    pm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean")
+    pm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean",
+                         pm_kernel=pm_kernel)
+    assert pm.pm_kernel_choice == pm_kernel
     sm = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
     obs, _ = pm.reset(options={"episodes": ep})
     sm.reset(options={"episodes": ep})
@@ -977,14 +981,16 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
         assert torch.equal(s1[k], s2[k]), k
     np.testing.assert_allclose(s1["episode_return"].cpu().numpy(), ret, rtol=2e-5, atol=1e-4)
     assert pm.check_status() == 0
-    print(f"posterior mean n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
+    print(f"posterior mean [{pm_kernel}] n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
     pm.close()
     sm.close()
 
 
-@pytest.mark.parametrize("kind,one_launch", [("bernoulli", True), ("threshold", True), ("table", True),
-                                             ("threshold", False), ("table", False)])
-def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch):
+@pytest.mark.parametrize("kind,one_launch,pm_kernel", [
+    ("bernoulli", True, "vector"), ("threshold", True, "vector"), ("table", True, "vector"),
+    ("threshold", False, "vector"), ("table", False, "vector"), ("bernoulli", True, "matrix"),
+    ("threshold", True, "auto")])
+def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_kernel):
     """rollout() with reward_mode='posterior_mean' -- the whole-episode kernel k_pm_rollout (one_launch) and the per-day
     sequence policy kernel + reward kernels + step kernel that serves what it does not -- against the
     oracle's policy loop on the all-draws reward: alerts, over-budget attempts and alert days exact, returns to f32
@@ -997,9 +1003,14 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch):
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, reward_mode="posterior_mean")
     n, gid0 = 700, 1000
     env = HeatAlertVecEnv(n, tables=ct, device=dev, env_gid0=gid0, similar_climate_counties=True,
-                          reward_mode="posterior_mean")
+                          reward_mode="posterior_mean", pm_kernel=pm_kernel)
     env.pm_rollout_kernel = one_launch
     env.reset(seed=21, options={"budget": 7})
+    if pm_kernel == "auto":  # both kernels were timed on this batch and the faster one kept
+        assert env.pm_kernel_choice in ("vector", "matrix") and set(env.pm_kernel_timing_us) == {"vector", "matrix"}
+        assert env.pm_kernel_timing_us[env.pm_kernel_choice] == min(env.pm_kernel_timing_us.values())
+    else:
+        assert env.pm_kernel_choice == pm_kernel  # "matrix": the one-launch kernel does not apply, per-day calls run
     st = _oracle_for_env(env, V)
     rng = np.random.default_rng(0)
     table = (rng.random((ct.T, 5)) < 0.3).astype(np.uint8)
@@ -1037,6 +1048,94 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch):
     stats = HeatAlertVecEnv.episode_stats(out)
     assert out["done"].all() and "average_t_alerts" in stats
     assert env.check_status() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_launch):
+    """k_pm_rollout's effectiveness loop beyond what the small case reaches: 3 coefficient columns x ~500 envs (full
+    512-row tiles and partial ones), 100 posterior draws (close to the 112 one staging pass holds), an always-alert
+    policy with a large budget, i.e. far more than 64 open-gate alerts per tile and day (several row groups, R = 4,
+    s_ax / s_part reuse). One launch and the per-day sequence against the oracle's policy loop on the all-draws reward."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=3, years=[2006, 2007], n_samples=100, seed=41)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    n = 1500 + 11
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean",
+                          pm_kernel="vector")
+    env.pm_rollout_kernel = one_launch
+    env.reset(seed=8, options={"budget": 120})
+    _oracle_for_env(env, V)
+    pol = dict(kind="always")
+    days = 24
+    out = env.rollout(pol, n_steps=days, alert_mask=True)
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, pol, days, None)
+    assert al_o.min() == days  # every env alerts every day: about half of them with an open gate
+    np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
+    np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-4)
+    assert env.check_status() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_posterior_mean_rollout_after_a_masked_reset(dev, one_launch):
+    """reward_mode='posterior_mean' with autoreset='disabled' after a masked reset: the batch has left lock step (half
+    the envs are on day 30, half on day 0). rollout() must serve every env on its own day and episode length -- envs
+    that finish early take no further part: no second terminal step, no reward added to a finished return."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=20, years=[2006, 2007], n_samples=6, seed=43, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    rd = O.RefData.from_synth(sd)
+    n, gid0 = 600, 50
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean", env_gid0=gid0,
+                          pm_kernel="vector")
+    env.pm_rollout_kernel = one_launch
+    env.reset(seed=3, options={"budget": 6})
+    rng = np.random.default_rng(1)
+    VA = O.VectorOracle(rd, sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    st = _oracle_for_env(env, VA)
+    retA = np.zeros(n)
+    for _ in range(30):
+        a = (rng.random(n) < 0.1).astype(np.int32)
+        env.step(torch.as_tensor(a, device=dev))
+        retA += VA.step(a)[1]
+    mask = np.arange(n) % 2 == 1
+    env.reset(seed=4, options={"mask": mask, "budget": 6})
+    assert not env._lockstep
+    s1 = {k: v.cpu().numpy() for k, v in env.state().items()}
+    assert (s1["t"][mask] == 0).all() and (s1["t"][~mask] == 30).all()
+    # oracle B: the re-drawn half from day 0; oracle A keeps going for the other half
+    VB = O.VectorOracle(rd, sd.fips_weather, sd.years, reward_mode="posterior_mean")
+    VB.reset(s1["county_w"][mask], s1["year_i"][mask], s1["coef_col"][mask], s1["sample"][mask], s1["budget"][mask])
+    VB._finished = np.zeros(int(mask.sum()), bool)
+    pol = dict(kind="bernoulli", p=0.2, seed=77)
+    idxA, idxB = np.nonzero(~mask)[0], np.nonzero(mask)[0]
+    drawA = lambda i, t: O.devrng_policy_uniform(77, gid0 + int(idxA_all[i]), int(s1["episode_no"][idxA_all[i]]), t)  # noqa: E731
+    idxA_all = np.arange(n)  # oracle A still holds all n envs; only the un-reset half is compared
+    drawB = lambda i, t: O.devrng_policy_uniform(77, gid0 + int(idxB[i]), int(s1["episode_no"][idxB[i]]), t)  # noqa: E731
+    out = env.rollout(pol, alert_mask=True)
+    rA, alA, ovA, dA = O.oracle_rollout(VA, pol, ct.T, drawA)
+    rB, alB, ovB, dB = O.oracle_rollout(VB, pol, ct.T, drawB)
+    assert out["done"].all()
+    g = {k: out[k].cpu().numpy() for k in ("return", "alerts", "attempts_over_budget", "alert_days", "final_return")}
+    np.testing.assert_array_equal(g["alerts"][idxA], alA[idxA])
+    np.testing.assert_array_equal(g["alerts"][idxB], alB)
+    np.testing.assert_array_equal(g["attempts_over_budget"][idxA], ovA[idxA])
+    np.testing.assert_array_equal(g["attempts_over_budget"][idxB], ovB)
+    np.testing.assert_array_equal(g["alert_days"][idxA], dA[idxA])
+    np.testing.assert_array_equal(g["alert_days"][idxB], dB)
+    np.testing.assert_allclose(g["return"][idxA], rA[idxA], rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g["return"][idxB], rB, rtol=2e-5, atol=1e-3)
+    # the finished half's return was not touched again while the other half ran on
+    np.testing.assert_allclose(g["final_return"][idxA], (retA + rA)[idxA], rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g["final_return"][idxB], rB, rtol=2e-5, atol=1e-3)
+    s2 = {k: v.cpu().numpy() for k, v in env.state().items()}
+    assert (s2["finished"] == 1).all() and (s2["t"] == s2["n_days"] - 1).all()
     env.close()
 
 
@@ -1106,6 +1205,19 @@ def test_posterior_mean_lockstep_autoreset_and_guards(dev):
         a = torch.zeros(n, dtype=torch.int32, device=dev)
         rc = lib.w2a_posterior_mean_reward(env._h, a.data_ptr(), _ffi.ACT_I32, env._reward.data_ptr(), env._stream())
     assert rc == -4 and b"w2a_group_by_column" in lib.w2a_last_error()
+    # ... and so must the relabelling sort and an autoreset step: both change which episode an env index holds
+    with torch.cuda.device(dev):
+        _ffi.check(lib.w2a_group_by_column(env._h, env._group_ws.data_ptr(), env._group_ws.numel(), env._stream()), "group")
+        assert lib.w2a_posterior_mean_reward(env._h, a.data_ptr(), _ffi.ACT_I32, env._reward.data_ptr(), env._stream()) == 0
+        ws = torch.empty(lib.w2a_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _ffi.check(lib.w2a_sort_episodes(env._h, ws.data_ptr(), ws.numel(), env._stream()), "sort")
+        assert lib.w2a_posterior_mean_reward(env._h, a.data_ptr(), _ffi.ACT_I32, env._reward.data_ptr(), env._stream()) == -4
+        _ffi.check(lib.w2a_group_by_column(env._h, env._group_ws.data_ptr(), env._group_ws.numel(), env._stream()), "group")
+        _ffi.check(lib.w2a_set_autoreset(env._h, 1, -1, 1, -1, 0, 1), "set_autoreset")
+        _ffi.check(lib.w2a_step(env._h, a.data_ptr(), _ffi.ACT_I32, env._obs.data_ptr(), env._reward.data_ptr(),
+                                env._done.data_ptr(), None, _ffi.STEP_AUTORESET, env._stream()), "step")
+        assert lib.w2a_posterior_mean_reward(env._h, a.data_ptr(), _ffi.ACT_I32, env._reward.data_ptr(), env._stream()) == -4
+    torch.cuda.synchronize()
     env.close()
     with pytest.raises(ValueError):
         HeatAlertVecEnv(8, tables=ct, device=dev, reward_mode="posterior_mean", fixes={"lag"})

@@ -158,3 +158,222 @@ def test_baseline_shapes_vs_oracle(dev, config, weights, n, augment, kernel):
     assert env.check_status() == 0
     print(f"{config} {weights} n={n} kernel={kernel}: sample {len(idx)} envs, max |reward - oracle| = {worst:.3e}")
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# every other path bench.py quotes at 1 048 576 envs: the on-device rollout with its visiting order, the
+# posterior-mean reward (step and whole-episode rollout, vector and matrix kernels) and episode_order="sorted".
+# Position arithmetic, tile-list sizing and the per-XCD tile walk only break at this size.
+# ---------------------------------------------------------------------------------------------------------------
+def _sample(n, k):
+    """~k env ids, strided, always including env 0 and the LAST env."""
+    return np.unique(np.concatenate([np.arange(0, n, max(n // k, 1)), [n - 1]]))
+
+
+class _Draw:
+    """Bernoulli-policy uniforms of the sampled envs (the build's counter RNG, restated in the oracle)."""
+
+    def __init__(self, seed, gids, episode_no):
+        self.seed, self.gids, self.ep = seed, np.asarray(gids, np.uint64), np.asarray(episode_no, np.uint64)
+
+    def vec(self, t):
+        return O.devrng_policy_uniform_vec(self.seed, self.gids, self.ep, t)
+
+    def __call__(self, i, t):
+        return O.devrng_policy_uniform(self.seed, int(self.gids[i]), int(self.ep[i]), t)
+
+
+@pytest.mark.parametrize("kind", ["threshold", "bernoulli"])
+def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
+    """rollout() at BASELINE configs[2] size (1 048 576 envs, S = 746, 100 draws, similar_climate_counties) through
+    k_rollout64 + the counting-sort visiting order (w2a_rollout_order), whole episode in one launch, against the
+    oracle's policy loop on ~8 192 sampled envs (incl. env 0 and the last one): alerts, over-budget attempts, alert-day
+    and attempt-day bitmaps exact, returns <= 2e-5 relative; every env finished; the order is a permutation."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("linear", dev)
+    V.reward_mode = "sampled"
+    n, gid0 = 1 << 20, 12345
+    env = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=True, autoreset="disabled", env_gid0=gid0,
+                          rollout_order=True)
+    env.reset(seed=31)
+    idx = _sample(n, 8192)
+    it = torch.as_tensor(idx, device=dev)
+    st = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+    V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    V._finished = np.zeros(len(idx), bool)
+    if kind == "threshold":
+        pol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
+        draw = None
+    else:
+        pol = dict(kind="bernoulli", p=0.1, seed=99)
+        draw = _Draw(99, gid0 + idx, st["episode_no"])
+        np.testing.assert_array_equal(draw.vec(np.full(len(idx), 3))[:5], [draw(i, 3) for i in range(5)])
+    out = env.rollout(pol, alert_mask=True)
+    assert env._order_ws is not None and not env._order_stale  # the lane = env kernel ran on the visiting order
+    order = env._order_ws[: 4 * n].view(torch.int32)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device=dev))  # a permutation of the env ids
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, dict(pol, col=ct.columns.index("heat_qi")), ct.T, draw)
+    np.testing.assert_array_equal(out["alerts"][it].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["attempts_over_budget"][it].cpu().numpy(), ov_o)
+    np.testing.assert_array_equal(out["alert_days"][it].cpu().numpy(), days_o)
+    got = out["return"][it].cpu().numpy().astype(np.float64)
+    rel = np.abs(got - ret_o).max() / np.abs(ret_o).max()
+    np.testing.assert_allclose(got, ret_o, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(out["final_return"][it].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-4)
+    assert bool(out["done"].all()) and int(out["alerts"].sum()) > n // 2  # all 1 048 576 envs ran to their last day
+    s2 = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+    np.testing.assert_array_equal(s2["used"], V.used)
+    np.testing.assert_array_equal(s2["streak"], V.streak)
+    np.testing.assert_array_equal(s2["t"], V.t)
+    # invariants over ALL envs: alerts never exceed the budget, attempts over budget only once the budget is used up
+    sa = env.state()
+    assert bool((sa["used"] <= sa["budget"]).all()) and bool((out["alerts"] == sa["used"]).all())
+    assert bool(((out["attempts_over_budget"] == 0) | (sa["used"] == sa["budget"])).all())
+    assert env.check_status() == 0
+    print(f"full-size rollout [{kind}]: sample {len(idx)} envs, max rel |return - oracle| = {rel:.3e}")
+    env.close()
+
+
+@pytest.mark.parametrize("pm_kernel", ["vector", "matrix"])
+def test_full_size_posterior_mean_step_vs_oracle(dev, pm_kernel):
+    """reward_mode='posterior_mean' step() at 1 048 576 envs on the nn_full_medicare_all shape (S = 720, 100 draws:
+    BASELINE configs[3], the 'dense reward GEMM'), both kernels of the library, 20 days against the oracle's mean over
+    all 100 draws on ~4 096 sampled envs (incl. env 0 and the last): w2a_group_by_column's radix sort, tile list and
+    per-XCD tile walk at full size. Reward <= 1e-5, observations and integer state exact."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("nn_full_medicare_all", dev)
+    V.reward_mode = "posterior_mean"
+    try:
+        n = 1 << 20
+        env = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled", reward_mode="posterior_mean",
+                              pm_kernel=pm_kernel)
+        obs, _ = env.reset(seed=17)
+        idx = _sample(n, 4096)
+        it = torch.as_tensor(idx, device=dev)
+        st = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+        assert len(np.unique(st["coef_col"])) > 700  # the sample spans the coefficient table
+        obs_o = V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+        np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+        g = torch.Generator(device=dev).manual_seed(9)
+        worst = 0.0
+        for t in range(20):
+            a = (torch.rand(n, device=dev, generator=g) < 0.3).to(torch.int32)
+            obs, r, done, _, _ = env.step(a)
+            obs_o, r_o, done_o, _ = V.step(a[it].cpu().numpy())
+            err = np.abs(r[it].cpu().numpy().astype(np.float64) - r_o).max()
+            worst = max(worst, err)
+            assert err <= REWARD_TOL, (t, err)
+            np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+            assert torch.isfinite(r).all() and float(r.max()) < 0.0  # every env got a reward (none skipped)
+        s2 = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+        np.testing.assert_array_equal(s2["used"], V.used)
+        np.testing.assert_array_equal(s2["streak"], V.streak)
+        assert env.check_status() == 0
+        print(f"full-size posterior mean step [{pm_kernel}]: sample {len(idx)} envs, max |reward - oracle| = {worst:.3e}")
+        env.close()
+    finally:
+        V.reward_mode = "sampled"
+
+
+def test_full_size_posterior_mean_rollout_vs_oracle(dev):
+    """rollout() through k_pm_rollout (one launch per episode) at 1 048 576 envs, S = 746, 100 draws, augmented:
+    whole episode against the oracle's policy loop on the all-draws reward for ~1 024 sampled envs; the per-day
+    sequence on the matrix kernel agrees with it on every env for the first days."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("linear", dev)
+    V.reward_mode = "posterior_mean"
+    try:
+        n, gid0 = 1 << 20, 777
+        env = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=True, autoreset="disabled",
+                              reward_mode="posterior_mean", pm_kernel="vector", env_gid0=gid0)
+        env.reset(seed=23)
+        idx = _sample(n, 1024)
+        it = torch.as_tensor(idx, device=dev)
+        st = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+        V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+        V._finished = np.zeros(len(idx), bool)
+        pol = dict(kind="bernoulli", p=0.1, seed=5)
+        draw = _Draw(5, gid0 + idx, st["episode_no"])
+        # a second env with the same episodes: the matrix kernel through the per-day sequence, first 3 days
+        e2 = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=True, autoreset="disabled",
+                             reward_mode="posterior_mean", pm_kernel="matrix", env_gid0=gid0)
+        e2.reset(seed=23)
+        o1 = env.rollout(pol, n_steps=3)
+        o2 = e2.rollout(pol, n_steps=3)
+        assert torch.equal(o1["alerts"], o2["alerts"])
+        torch.testing.assert_close(o1["return"], o2["return"], rtol=1e-5, atol=1e-5)
+        e2.close()
+        r1, a1, v1, _ = O.oracle_rollout(V, pol, 3, draw)
+        out = env.rollout(pol, alert_mask=True)
+        r2, a2, v2, days_o = O.oracle_rollout(V, pol, ct.T, draw)
+        assert bool(out["done"].all()) and bool((out["first_day"] == 3).all())
+        np.testing.assert_array_equal((o1["alerts"] + out["alerts"])[it].cpu().numpy(), a1 + a2)
+        np.testing.assert_array_equal((o1["attempts_over_budget"] + out["attempts_over_budget"])[it].cpu().numpy(), v1 + v2)
+        np.testing.assert_array_equal(out["alert_days"][it].cpu().numpy()[:, 3:], days_o[:, 3:])
+        np.testing.assert_allclose(o1["return"][it].cpu().numpy(), r1, rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(out["return"][it].cpu().numpy(), r2, rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(out["final_return"][it].cpu().numpy(), r1 + r2, rtol=2e-5, atol=1e-4)
+        assert env.check_status() == 0
+        env.close()
+    finally:
+        V.reward_mode = "sampled"
+
+
+def test_full_size_sorted_episode_order_vs_oracle(dev):
+    """episode_order='sorted' at 1 048 576 envs (S = 746, augmented): the relabelled batch holds the same multiset of
+    episode records as the iid order for the same seed, env indices follow the coefficient rows, and one whole
+    episode steps like the oracle on a strided sample (incl. env 0 and the last env)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("linear", dev)
+    V.reward_mode = "sampled"
+    n = 1 << 20
+    kw = dict(tables=dt, device=dev, similar_climate_counties=True)
+    iid = HeatAlertVecEnv(n, autoreset="disabled", **kw)
+    srt = HeatAlertVecEnv(n, episode_order="sorted", **kw)
+    iid.reset(seed=5)
+    obs, _ = srt.reset(seed=5)
+    keys = ("county_w", "year_i", "coef_col", "sample", "budget", "sticky_budget", "episode_no")
+
+    def packed(e):  # one int64 key per env: the whole record (field widths: 10, 4, 10, 7, 16, 16 bits; episode_no = 0)
+        s = e.state()
+        assert int(s["episode_no"].max()) == 0 and int(s["budget"].max()) < 65535 and int(s["sticky_budget"].max()) < 65535
+        k = s["county_w"].long()
+        for name, bits in (("year_i", 4), ("coef_col", 10), ("sample", 7), ("budget", 16), ("sticky_budget", 16)):
+            k = (k << bits) | (s[name].long() + (1 if name == "sticky_budget" else 0))
+        return k
+
+    ka, kb = packed(iid), packed(srt)
+    assert torch.equal(torch.sort(ka).values, torch.sort(kb).values)  # same multiset of episode records
+    sb = srt.state()
+    row = ((sb["coef_col"].long() << 12 | sb["sample"].long()) << 32) | (sb["county_w"].long() * ct.Y + sb["year_i"].long())
+    assert bool((row[1:] >= row[:-1]).all()) and not torch.equal(ka, kb)
+    iid.close()
+    idx = _sample(n, 16384)
+    it = torch.as_tensor(idx, device=dev)
+    st = {k: v[it].cpu().numpy() for k, v in sb.items()}
+    obs_o = V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+    g = torch.Generator(device=dev).manual_seed(2)
+    ret = np.zeros(len(idx))
+    for t in range(153):
+        a = (torch.rand(n, device=dev, generator=g) < 0.15).to(torch.int32)
+        obs, r, done, _, info = srt.step(a)
+        obs_o, r_o, done_o, _ = V.step(a[it].cpu().numpy())
+        assert np.abs(r[it].cpu().numpy() - r_o).max() <= REWARD_TOL
+        np.testing.assert_array_equal(done[it].cpu().numpy(), done_o)
+        ret += r_o
+        if t < 152:
+            np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+    assert bool(done.all())
+    np.testing.assert_allclose(info["final_return"][it].cpu().numpy(), ret, rtol=2e-5)
+    # the lock-step autoreset relabelled the next episode too
+    s3 = srt.state()
+    assert bool((s3["episode_no"] == 1).all()) and bool((s3["t"] == 0).all())
+    row = ((s3["coef_col"].long() << 12 | s3["sample"].long()) << 32) | (s3["county_w"].long() * ct.Y + s3["year_i"].long())
+    assert bool((row[1:] >= row[:-1]).all())
+    assert srt.check_status() == 0
+    srt.close()

@@ -11,9 +11,9 @@ ROW_FLOATS = 32
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE = 1, 2, 8, 16, 32
+STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED = 1, 2, 8, 16, 32, 64
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 8
+ABI_VERSION = 9
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -22,8 +22,9 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
-    "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward",
+    "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward", "w2a_set_posterior_kernel",
 ]
+PM_KERNELS = {"vector": 0, "matrix": 1}  # W2A_PM_VECTOR, W2A_PM_MATRIX_F64
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
 
 
@@ -73,8 +74,9 @@ def load(build_if_missing: bool = True):
         try:
             _build.build_lib()
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise W2AError(f"libw2a.so is missing and could not be built: {e}") from e
+            # never fall back to an older library when its sources have changed: the ABI version check below would
+            # accept a stale .so whose kernels differ from the sources in the tree
+            raise W2AError(f"libw2a.so is out of date (or missing) and could not be rebuilt: {e}") from e
     if not os.path.exists(path):
         raise W2AError(f"{path} not found: run `python -m weather2alert_amd.build` (there is no CPU fallback)")
     lib = C.CDLL(path)
@@ -111,6 +113,8 @@ def load(build_if_missing: bool = True):
     lib.w2a_group_by_column.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_posterior_mean_reward.restype = C.c_int
     lib.w2a_posterior_mean_reward.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.w2a_set_posterior_kernel.restype = C.c_int
+    lib.w2a_set_posterior_kernel.argtypes = [vp, C.c_int]
     lib.w2a_observe.restype = C.c_int
     lib.w2a_observe.argtypes = [vp, vp, vp]
     lib.w2a_set_semantics.restype = C.c_int

@@ -159,6 +159,7 @@ struct w2a_env {
   const uint32_t *n_tiles;
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
+  int pm_kernel;         // W2A_PM_* : which posterior-mean reward kernel w2a_posterior_mean_reward launches
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };
 

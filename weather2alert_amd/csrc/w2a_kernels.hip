@@ -4,8 +4,8 @@
 //   reset  :133-184 (+ _get_episode :107-131)      -> draw_episode() / k_reset
 //   _get_obs :186-195, _get_reward :197-226, step :238-262 -> k_step (and k_rollout: many days per launch)
 // How it is computed is MI355X-first:
-//   * an env is served by a 4-lane group of a 64-wide wavefront (16 envs per wave, 64 per
-//     256-thread workgroup); lane l owns floats 8l..8l+7 of the env's 128-byte feature row
+//   * (k_step, k_reset, k_rollout) an env is served by a 4-lane group of a 64-wide wavefront (16 envs per wave, 64
+//     per 256-thread workgroup); lane l owns floats 8l..8l+7 of the env's 128-byte feature row
 //     and of its two 128-byte coefficient rows, so every gather is 16-B loads that together
 //     cover whole 128-B lines (LANES = 8 / 2 were measured slower);
 //   * feature rows are stored day-major ([T][county*year][32]); all envs of a lock-step
@@ -21,8 +21,9 @@
 //   * the effectiveness coefficient row is fetched only for envs that issue an alert today
 //     (it enters the reward through eff * actual, env.py:221): half the gather traffic;
 //   * workgroup -> env-tile mapping is XCD-aware (logical_block); k_step64 (w2a_step64.hip.h) is the lean
-//     64-envs-per-wave form of the same step for plain lock-step batches; the posterior-mean reward GEMM
-//     (k_posterior_mean) is the only MFMA user (fp64 16x16x4).
+//     64-envs-per-wave form of the same step for plain lock-step batches; the posterior-mean reward contraction
+//     (w2a_posterior.hip.h) exists as a vector-ALU kernel (default) and as matrix-unit (MFMA) kernels, selected at
+//     run time by w2a_set_posterior_kernel -- the only MFMA users of the library.
 //
 // No fallback path exists: without this library (or without a ROCm device) constructing an env raises.
 
@@ -170,6 +171,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->order = nullptr;
   h->prep = nullptr;
   h->perm_valid = 0;
+  h->pm_kernel = W2A_PM_VECTOR;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -261,11 +263,15 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
   if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
+  if (autoreset) env->perm_valid = 0;  // envs that finish draw new coefficient columns inside the kernel
   StepArgs a;
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
+  a.skip_finished = (flags & W2A_STEP_SKIP_FINISHED) ? 1 : 0;
+  if (a.skip_finished && !given)
+    return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_SKIP_FINISHED goes with W2A_STEP_REWARD_GIVEN (policy loops)");
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
 #if W2A_F64_SIGMOID
@@ -342,6 +348,7 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  env->perm_valid = 0;  // every env index now holds another episode: the column grouping is stale
   return W2A_OK;
 }
 
@@ -422,16 +429,24 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
-#if W2A_PM_MATRIX
-  const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
-  if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_posterior_mean<7>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
-#else
-  const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
-  if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean_v<8>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_posterior_mean_v<7>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
-#endif
+  if (env->pm_kernel == W2A_PM_MATRIX_F64) {
+    const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
+    if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_posterior_mean<7>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  } else {
+    const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
+    if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean_v<8>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_posterior_mean_v<7>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
+  }
   HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_set_posterior_kernel(w2a_env *env, int kernel) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_set_posterior_kernel: NULL handle");
+  if (kernel != W2A_PM_VECTOR && kernel != W2A_PM_MATRIX_F64)
+    return fail(W2A_ERR_ARG, "w2a_set_posterior_kernel: kernel must be W2A_PM_VECTOR or W2A_PM_MATRIX_F64");
+  env->pm_kernel = kernel;
   return W2A_OK;
 }
 
@@ -525,7 +540,9 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   if (!env->perm_valid)
     return fail(W2A_ERR_STATE, "w2a_rollout_posterior_mean: call w2a_group_by_column after every reset");
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: not available with corrected-semantics flags");
-  if (env->tb.n_samples > W2A_PMV_NPAD || env->w_tail_used || W2A_PM_MATRIX) return 1;  // not applicable: use the per-day calls
+  // not applicable (more draws than one staging pass holds, coefficients on slots 28/30/31, or the matrix kernel was
+  // selected: the one-launch kernel is built on the vector form): the caller runs the per-day calls
+  if (env->tb.n_samples > W2A_PMV_NPAD || env->w_tail_used || env->pm_kernel != W2A_PM_VECTOR) return 1;
   PmRolloutArgs pa;
   memset(&pa, 0, sizeof(pa));
   RolloutArgs &a = pa.r;

@@ -1,8 +1,8 @@
 // w2a_posterior.hip.h -- today's reward averaged over ALL posterior draws of the env's coefficient column (the
 // legacy env's eval mode, _deprecated/env.py:332-342, on today's linear-logistic form env.py:197-226): the pre-pass
-// k_pm_prep, the default kernel k_posterior_mean_v (fp64 vector FMAs, DPP-broadcast coefficients; second half of
-// this file) and the fp64-MFMA form k_posterior_mean (A/B build -DW2A_PM_MATRIX=1); k_group_keys / k_group_inverse /
-// k_pm_wd feed the once-per-episode grouping.
+// k_pm_prep, the kernel k_posterior_mean_v (fp64 vector FMAs, DPP-broadcast coefficients; second half of this file)
+// and the fp64-MFMA form k_posterior_mean; both are in the library and w2a_set_posterior_kernel selects one at run time
+// (W2A_PM_VECTOR / W2A_PM_MATRIX_F64). k_group_keys / k_group_inverse / k_pm_wd feed the once-per-episode grouping.
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
 #ifndef W2A_POSTERIOR_HIP_H
 #define W2A_POSTERIOR_HIP_H
@@ -32,9 +32,6 @@
 static_assert(PM_ROWS == BLOCK, "one thread per row in the set-up phase");
 #define PM_TILES_PER_WAVE (PM_ROWS / 16 / (BLOCK / 64))
 #define PM_NPAD 112                // draws per staging pass (7 MFMA column tiles)
-#ifndef W2A_PM_MATRIX
-#define W2A_PM_MATRIX 0            // A/B: 1 = the fp64-MFMA form (k_posterior_mean), 0 = the lane = env form (k_posterior_mean_v)
-#endif
 typedef double pm_double4 __attribute__((ext_vector_type(4)));
 
 struct PosteriorArgs {

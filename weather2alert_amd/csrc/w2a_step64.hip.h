@@ -242,7 +242,12 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   }
 
   // ---------------------------------------------------------------- phase C: lane = env
-  if (valid) {
+  if (valid && a.skip_finished && D1_FIN(h.b)) {
+    // W2A_STEP_SKIP_FINISHED: policy loops over batches that are not in lock step (w2a_policy_actions gave this env
+    // action 0): the finished episode's state, return and observation stay as they are
+    a.reward[e] = 0.0f;
+    a.done[e] = 1;
+  } else if (valid) {
   float r;
   if (REWARD_GIVEN) {
     r = a.reward[e];

@@ -74,8 +74,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
     reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
                          "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
-                         reward form -- computed by a grouped fp64-MFMA GEMM per step (csrc/w2a_posterior.hip.h).
+                         reward form -- one grouped contraction per step (csrc/w2a_posterior.hip.h).
                          Needs lock-step / disabled autoreset and faithful semantics.
+    pm_kernel            which kernel computes that contraction: "vector" (fp64 FMAs on the vector ALU with
+                         DPP-broadcast coefficients), "matrix" (fp64 matrix cores, v_mfma_f64_16x16x4_f64), or "auto"
+                         (default): both are timed once on this env's own batch after the first reset and the faster
+                         one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why).
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
                          64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
                          (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
@@ -113,6 +117,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         step_kernel: Literal["auto", "classic", "wide"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         rollout_order: bool = True,
+        pm_kernel: Literal["auto", "vector", "matrix"] = "auto",
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -159,6 +164,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if reward_mode == "posterior_mean" and (self.fixes or step_kernel == "classic"):
             raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
+        if pm_kernel not in ("auto", "vector", "matrix"):
+            raise ValueError(f"pm_kernel {pm_kernel!r}")
+        self.pm_kernel = pm_kernel
+        self.pm_kernel_choice = None if pm_kernel == "auto" else pm_kernel  # decided after the first reset
+        self.pm_kernel_timing_us: dict = {}
         self.rollout_order = bool(rollout_order)  # rollout() visits the envs in feature-row order (speed only; A/B)
         self.pm_rollout_kernel = True  # posterior_mean rollouts in one launch when possible (False: per-day launches)
         self._order_stale = True
@@ -196,6 +206,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
         bits = sum(_ffi.FIX_BITS[k] for k in self.fixes if k in _ffi.FIX_BITS)
         if bits:
             _ffi.check(self._lib.w2a_set_semantics(h, bits), "w2a_set_semantics")
+        if reward_mode == "posterior_mean" and self.pm_kernel_choice is not None:
+            _ffi.check(self._lib.w2a_set_posterior_kernel(h, _ffi.PM_KERNELS[self.pm_kernel_choice]),
+                       "w2a_set_posterior_kernel")
         # hot-path constants (step() is called millions of times: no per-call attribute chains)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._obs_ptr = self._obs.data_ptr() if self.write_obs else None
@@ -533,6 +546,33 @@ class HeatAlertVecEnv(_VectorEnvBase):
             with torch.cuda.device(self.device):
                 _ffi.check(self._lib.w2a_group_by_column(self._h, self._group_ws.data_ptr(), self._group_ws.numel(),
                                                          self._stream()), "w2a_group_by_column")
+            if self.pm_kernel_choice is None:
+                self._pick_pm_kernel()
+
+    def _pick_pm_kernel(self, reps: int = 3):
+        """pm_kernel="auto": time w2a_posterior_mean_reward with each kernel on this env's own grouped batch (HIP
+        events on the launch stream, best of `reps`; the call only writes the reward buffer and its scratch) and keep
+        the faster one. Runs once per env, right after the first grouping."""
+        act = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        best = {}
+        with torch.cuda.device(self.device):
+            for name, code in _ffi.PM_KERNELS.items():
+                _ffi.check(self._lib.w2a_set_posterior_kernel(self._h, code), "w2a_set_posterior_kernel")
+                times = []
+                for _ in range(reps + 1):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _ffi.check(self._lib.w2a_posterior_mean_reward(self._h, act.data_ptr(), _ffi.ACT_I32, self._rew_ptr,
+                                                                   self._stream()), "w2a_posterior_mean_reward")
+                    e1.record()
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1) * 1e3)
+                best[name] = min(times[1:])
+            self.pm_kernel_timing_us = best
+            self.pm_kernel_choice = min(best, key=best.get)
+            _ffi.check(self._lib.w2a_set_posterior_kernel(self._h, _ffi.PM_KERNELS[self.pm_kernel_choice]),
+                       "w2a_set_posterior_kernel")
+            self.check_status()  # zero actions on a fresh episode raise no status bit; clear what a mid-episode call may
 
     # ------------------------------------------------------------------ step
     def step(self, actions):
@@ -572,7 +612,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
     def rollout(self, policy: dict, n_steps: int | None = None, alert_mask: bool = False) -> dict:
         """Run a built-in policy inside the kernel for ``n_steps`` days (default: to the end of the episode)
         without returning to Python between days (replaces loops like env.py:265-277). With
-        reward_mode="posterior_mean" the days are a host loop of policy kernel + reward kernels + step kernel (same
+        reward_mode="posterior_mean" the whole rollout is one launch of k_pm_rollout (vector kernel, <= 112 posterior
+        draws, reference schema); otherwise a host loop of policy kernel + reward kernels + step kernel per day (same
         policies, same outputs): the legacy eval mode's evaluation sweep.
 
         policy: {"kind": "never" | "always"} |
@@ -653,16 +694,18 @@ class HeatAlertVecEnv(_VectorEnvBase):
         return out
 
     def _rollout_posterior_mean(self, p, steps, out, mask, amask, words, snap, st0) -> int:
-        """rollout() with reward_mode="posterior_mean": per day w2a_policy_actions (the policy and counters of
-        k_rollout), w2a_posterior_mean_reward, w2a_step(REWARD_GIVEN). The batch is in lock step (checked by the
-        constructor), so the day and the episode length are those of env 0. Returns the number of days run."""
+        """rollout() with reward_mode="posterior_mean": one launch of k_pm_rollout when it applies, else per day
+        w2a_policy_actions (the policy and counters of k_rollout), w2a_posterior_mean_reward, w2a_step(REWARD_GIVEN |
+        SKIP_FINISHED). Every env is handled on its own day and its own episode length (batches that left lock step
+        under autoreset="disabled", ragged episode lengths): envs whose episode is over take no part. Returns the
+        number of days run = the most any env had left, capped by `steps`."""
         for k in ("return", "alerts", "attempts_over_budget"):
             out[k].zero_()
         for m in (mask, amask):
             if m is not None:
                 m.zero_()
-        t0, n_days, fin = int(st0["t"][0]), int(st0["n_days"][0]), bool(st0["finished"][0])
-        steps = 0 if fin else min(steps, n_days - t0)
+        left = torch.where(st0["finished"].bool(), torch.zeros_like(st0["t"]), st0["n_days"] - st0["t"])
+        steps = min(steps, int(left.max()))
         lib, h, stream = self._lib, self._h, self._stream()
         if steps and self.pm_rollout_kernel:  # the whole rollout in one launch, when the kernel applies
             rc = lib.w2a_rollout_posterior_mean(h, C.byref(p), steps, out["return"].data_ptr(), out["alerts"].data_ptr(),
@@ -675,7 +718,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
             if rc != 1:
                 _ffi.check(rc, "w2a_rollout_posterior_mean")
         act = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
-        for k in range(steps):
+        flags = self._step_flags | _ffi.STEP_NO_OBS | _ffi.STEP_SKIP_FINISHED
+        nd2 = st0["n_days"] - 2
+        for _ in range(steps):
             _ffi.check(lib.w2a_policy_actions(h, C.byref(p), act.data_ptr(), out["alerts"].data_ptr(),
                                               out["attempts_over_budget"].data_ptr(),
                                               None if mask is None else mask.data_ptr(),
@@ -683,12 +728,15 @@ class HeatAlertVecEnv(_VectorEnvBase):
                        "w2a_policy_actions")
             _ffi.check(lib.w2a_posterior_mean_reward(h, act.data_ptr(), _ffi.ACT_I32, self._rew_ptr, stream),
                        "w2a_posterior_mean_reward")
-            # like k_rollout, no observation rows are written (the next step() or reset() brings them up to date)
+            # like k_rollout, no observation rows are written (the next step() or reset() brings them up to date);
+            # finished envs are skipped: their reward comes back as 0 and their state stays
             _ffi.check(self._w2a_step(h, act.data_ptr(), _ffi.ACT_I32, None, self._rew_ptr, self._done_ptr,
-                                      self._fr_ptr, self._step_flags | _ffi.STEP_NO_OBS, stream), "w2a_step")
+                                      self._fr_ptr, flags, stream), "w2a_step")
             out["return"] += self._reward
-            if snap is not None and t0 + k + 1 == n_days - 2:  # the moment the reference's callbacks read the env
-                snap.copy_(self.state()["episode_return"])
+            if snap is not None:  # per env: the moment the reference's callbacks read it (t == n_days - 2 after a step)
+                st = self.state()
+                hit = (st["t"] == nd2) & (st["finished"] == 0) & torch.isnan(snap)
+                torch.where(hit, st["episode_return"], snap, out=snap)
         self._keep_act = act
         return steps
 
