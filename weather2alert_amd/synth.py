@@ -158,10 +158,13 @@ class SynthData:
 
 
 def make_state_arrays(S_w: int, years: list[int], n_days: int, rng: np.random.Generator,
-                      alert_rate: float = 0.05):
-    """Dense state tables following merge_state_actions.py:121-210 on synthetic weather."""
+                      alert_rate: float = 0.05, round_f32: bool = True):
+    """Dense state tables following merge_state_actions.py:121-210 on synthetic weather. round_f32=False leaves the
+    ranks, rolling means, products and standardised splines in float64, as the reference's ETL produces them (the
+    real HF parquet is float64 and not float32-representable)."""
     Y, T = len(years), n_days
     L = Y * T
+    _f32 = globals()["_f32"] if round_f32 else (lambda a: np.asarray(a, dtype=np.float64))  # noqa: N806
     hi_max = _f32(rng.uniform(0.5, 1.2, size=(S_w, L)))
     # percentile rank per county over its whole series (groupby fips, rank(pct=True))
     order = np.argsort(np.argsort(hi_max, axis=1, kind="stable"), axis=1)
@@ -191,7 +194,7 @@ def make_state_arrays(S_w: int, years: list[int], n_days: int, rng: np.random.Ge
     u = (dos / M) / (M + 1.0)
     bs = np.stack([3 * u * (1 - u) ** 2, 3 * u**2 * (1 - u), u**3], axis=1)
     bs = (bs - bs.mean(axis=0)) / bs.std(axis=0, ddof=1)
-    exo = np.empty((S_w, L, len(EXO_COLS)), dtype=np.float32)
+    exo = np.empty((S_w, L, len(EXO_COLS)), dtype=np.float32 if round_f32 else np.float64)
     cols = {
         "heat_qi": heat_qi,
         "heat_qi_above_25": hq25,
@@ -289,6 +292,7 @@ def make_synth(
     weight_scale: dict[str, float] | None = DEFAULT_SCALE,
     weight_sigma: float = 0.3,
     extra_confounder_fips: int = 0,
+    round_f32: bool = True,
 ) -> SynthData:
     """Synthetic data set shaped like the reference's.
 
@@ -317,7 +321,7 @@ def make_synth(
             pick[0] = fips_list.index("06037")
             pick = sorted(pick)
         fips_weather = [fips_list[i] for i in pick]
-    arrays = make_state_arrays(len(fips_weather), years, n_days, rng)
+    arrays = make_state_arrays(len(fips_weather), years, n_days, rng, round_f32=round_f32)
     weights = make_weights(len(fips_list), n_samples, rng, weight_scale, weight_sigma)
     # confounders: every weight county + a few outsiders, shuffled (its row order defines the
     # order of the "similar counties" list, datautils.py:124)

@@ -333,7 +333,11 @@ def compile_from_synth(d, sorted_keys: bool = True) -> CompiledTables:
             continue
         Xv[..., slot_of[c]] = np.moveaxis(np.asarray(getattr(d, c), np.float32), 2, 0)
     Xv[..., SLOT_BIAS] = 1.0
-    Xv[..., SLOT_GATE] = (Xv[..., slot_of["heat_qi"]] > 0.5).astype(np.float32)  # 0/1 gate flag (env.py:218)
+    # 0/1 gate flag (env.py:218), decided on the data's own (possibly float64) value, not on its float32 copy
+    Xv[..., SLOT_GATE] = np.moveaxis(d.exo[..., list(exo_cols).index("heat_qi")] > 0.5, 2, 0).astype(np.float32)
+    f32_exact = bool(np.array_equal(d.exo.astype(np.float32).astype(np.float64), d.exo.astype(np.float64)) and all(
+        np.array_equal(np.asarray(getattr(d, c), np.float32).astype(np.float64), np.asarray(getattr(d, c), np.float64))
+        for c in endo_cols if c not in RUNTIME_COLS))
     n_days = np.full(S_w * Y, T, np.int64)
     ragged = d.meta.get("n_days_per_episode")  # optional [S_w, Y] episode lengths (0 = pair absent)
     if ragged is not None:
@@ -342,7 +346,7 @@ def compile_from_synth(d, sorted_keys: bool = True) -> CompiledTables:
         X[dead] = 0.0
     B0 = np.where(n_days > 0, d.remaining_budget[:, :, 0].reshape(-1), 0).astype(np.int64)
     return _finish(columns, d.fips_weather, d.years, T, X, n_days, B0, post, d.fips_list, d.confounder_fips,
-                   d.confounder_zone, d.meta.get("sig_categories", []), True, slot_of, obs_slot)
+                   d.confounder_zone, d.meta.get("sig_categories", []), f32_exact, slot_of, obs_slot)
 
 
 # ------------------------------------------------------------------------------------------
