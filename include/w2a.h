@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 9
+#define W2A_ABI_VERSION 10
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -189,11 +189,14 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
  *                              (env.py:242-246): an alert attempted at budget counts as no alert. */
 /*   w2a_set_posterior_kernel   which kernel computes the contraction (same results to ~1e-7; speed differs):
  *                              W2A_PM_VECTOR (default) fp64 FMAs on the vector ALU with DPP-broadcast coefficients,
- *                              W2A_PM_MATRIX_F64 the fp64 matrix-core form (v_mfma_f64_16x16x4_f64). On MI355X the fp64
- *                              matrix rate equals the fp64 vector rate, so the vector form is the faster one; the
- *                              choice also decides whether w2a_rollout_posterior_mean's one-launch kernel applies
+ *                              W2A_PM_MATRIX_F64 the fp64 matrix-core form (v_mfma_f64_16x16x4_f64; on MI355X the fp64
+ *                              matrix rate equals the fp64 vector rate, so it is the slower of the two),
+ *                              W2A_PM_MATRIX_I8 the int8 matrix-core form (v_mfma_i32_16x16x64_i8 on exact fixed-point
+ *                              digits of both operands, int32 accumulation; logits within ~2e-6 by an a-priori bound,
+ *                              columns outside the fixed-point range take an exact fp64 path inside the kernel).
+ *                              The choice also decides whether w2a_rollout_posterior_mean's one-launch kernel applies
  *                              (it is built on the vector form). */
-enum { W2A_PM_VECTOR = 0, W2A_PM_MATRIX_F64 = 1 };
+enum { W2A_PM_VECTOR = 0, W2A_PM_MATRIX_F64 = 1, W2A_PM_MATRIX_I8 = 2 };
 int w2a_set_posterior_kernel(w2a_env *env, int kernel);
 size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples);
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);

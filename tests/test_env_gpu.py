@@ -991,11 +991,13 @@ def test_other_schema_parity(dev):
     (3000 + 5, 48, 12, True, False, False), (37, 30, 100, False, False, False), (4096, 746, 100, True, False, False),
     (2048 + 9, 40, 20, True, True, False), (1500 + 3, 48, 12, True, False, True),
     (1500 + 7, 3, 130, False, False, False)])
-@pytest.mark.parametrize("pm_kernel", ["vector", "matrix"])
+@pytest.mark.parametrize("pm_kernel", ["vector", "matrix", "matrix_i8"])
 def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment, adversarial, tail, pm_kernel):
     """reward_mode='posterior_mean' (legacy eval mode, _deprecated/env.py:332-342, on today's reward form): the
     grouped contraction + sigmoid/mean epilogue -- BOTH kernels of the one library, selected at run time: the
-    vector-ALU form (v_fmac_f64_dpp) and the matrix-core form (v_mfma_f64_16x16x4_f64) -- against the oracle's mean over every posterior draw; everything
+    vector-ALU form (v_fmac_f64_dpp), the fp64 matrix-core form (v_mfma_f64_16x16x4_f64) and the int8 matrix-core form
+    (v_mfma_i32_16x16x64_i8 on fixed-point digits; the adversarial case flags every column, i.e. runs its exact fp64
+    path) -- against the oracle's mean over every posterior draw; everything
     but the reward (observations, integer state, termination) equals the sampled-reward env. Ragged draw counts
     (12: a partial 16-column MFMA tile), tiles that span many coefficient columns (n = 37), the full 746-column
     table, augmentation (Q8: the coefficient column differs from the weather county), and 3 columns x 130 draws: column
@@ -1052,7 +1054,7 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
 @pytest.mark.parametrize("kind,one_launch,pm_kernel", [
     ("bernoulli", True, "vector"), ("threshold", True, "vector"), ("table", True, "vector"),
     ("threshold", False, "vector"), ("table", False, "vector"), ("bernoulli", True, "matrix"),
-    ("threshold", True, "auto")])
+    ("bernoulli", True, "matrix_i8"), ("table", True, "matrix_i8"), ("threshold", True, "auto")])
 def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_kernel):
     """rollout() with reward_mode='posterior_mean' -- the whole-episode kernel k_pm_rollout (one_launch) and the per-day
     sequence policy kernel + reward kernels + step kernel that serves what it does not -- against the
@@ -1070,7 +1072,7 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_ke
     env.pm_rollout_kernel = one_launch
     env.reset(seed=21, options={"budget": 7})
     if pm_kernel == "auto":  # both kernels were timed on this batch and the faster one kept
-        assert env.pm_kernel_choice in ("vector", "matrix") and set(env.pm_kernel_timing_us) == {"vector", "matrix"}
+        assert env.pm_kernel_choice in env.pm_kernel_timing_us and set(env.pm_kernel_timing_us) == {"vector", "matrix", "matrix_i8"}
         assert env.pm_kernel_timing_us[env.pm_kernel_choice] == min(env.pm_kernel_timing_us.values())
     else:
         assert env.pm_kernel_choice == pm_kernel  # "matrix": the one-launch kernel does not apply, per-day calls run

@@ -235,7 +235,7 @@ def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
     env.close()
 
 
-@pytest.mark.parametrize("pm_kernel", ["vector", "matrix"])
+@pytest.mark.parametrize("pm_kernel", ["vector", "matrix", "matrix_i8"])
 def test_full_size_posterior_mean_step_vs_oracle(dev, pm_kernel):
     """reward_mode='posterior_mean' step() at 1 048 576 envs on the nn_full_medicare_all shape (S = 720, 100 draws:
     BASELINE configs[3], the 'dense reward GEMM'), both kernels of the library, 20 days against the oracle's mean over

@@ -25,6 +25,8 @@ p.add_argument("--no-obs", action="store_true")
 p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
 p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"])
 p.add_argument("--reward-mode", default="sampled", choices=["sampled", "posterior_mean"])
+p.add_argument("--pm-kernel", default="vector", choices=["vector", "matrix", "matrix_i8"],
+               help="posterior-mean reward kernel (all are in the one library, selected at run time)")
 a = p.parse_args()
 wname, n_default, augment, desc = bench.WORKLOADS[a.workload]
 n = a.num_envs or n_default
@@ -32,7 +34,8 @@ dev = torch.device("cuda:0")
 sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
 env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=augment, write_obs=not a.no_obs,
-                      step_kernel=a.step_kernel, episode_order=a.episode_order, reward_mode=a.reward_mode)
+                      step_kernel=a.step_kernel, episode_order=a.episode_order, reward_mode=a.reward_mode,
+                      pm_kernel=a.pm_kernel)
 g = torch.Generator(device=dev).manual_seed(1234)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(8)]
 env.reset(seed=0)
@@ -54,7 +57,7 @@ from weather2alert_amd import build as wbuild  # noqa: E402
 
 os.makedirs("gpurun_out", exist_ok=True)
 tag = (a.workload + ("_noobs" if a.no_obs else "") + ("_sorted" if a.episode_order == "sorted" else "")
-       + ("_pm" if a.reward_mode == "posterior_mean" else ""))
+       + (("_pm_" + a.pm_kernel) if a.reward_mode == "posterior_mean" else ""))
 json.dump({"workload": tag, "src_sha": wbuild.source_sha(), "num_envs": n, "steps": a.steps,
            "step_kernel": env_kernel},
           open(f"gpurun_out/pmc_probe_{tag}.json", "w"))

@@ -157,6 +157,14 @@ struct w2a_env {
   const double *wd;      // fp64 copy of W scaled by -log2(e), in the same workspace
   const uint4 *tiles;    // tile list of the posterior-mean kernel, in the same workspace
   const uint32_t *n_tiles;
+  // int8 matrix-core form of the posterior-mean reward (w2a_posterior_i8.hip.h), in the same workspace
+  const uint4 *tiles_i8;
+  const uint32_t *n_tiles_i8;
+  const uint32_t *wq;
+  const float *wscale;
+  const uint32_t *colflag;
+  const float *xs;
+  const void *xmax_ws;   // workspace whose slot maxima (once-per-table scan) are valid
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
   int pm_kernel;         // W2A_PM_* : which posterior-mean reward kernel w2a_posterior_mean_reward launches

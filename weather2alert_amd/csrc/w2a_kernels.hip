@@ -39,6 +39,7 @@
 #include "w2a_step.hip.h"
 #include "w2a_step64.hip.h"
 #include "w2a_posterior.hip.h"
+#include "w2a_posterior_i8.hip.h"
 #include "w2a_reset.hip.h"
 #include "w2a_rollout.hip.h"
 #include "w2a_sort.hip.h"
@@ -172,6 +173,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->prep = nullptr;
   h->perm_valid = 0;
   h->pm_kernel = W2A_PM_VECTOR;
+  h->xmax_ws = nullptr;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -363,11 +365,18 @@ static size_t wd_bytes(int32_t S, int32_t n_samples) { return align256((size_t)S
 // tiles of the posterior-mean kernel: at most one partial tile per column on top of n / PMV_THREADS full ones
 static size_t max_tiles(int64_t n, int32_t S) { return (size_t)((n + PMV_THREADS - 1) / PMV_THREADS) + (size_t)S; }
 static size_t tile_bytes(int64_t n, int32_t S) { return align256(16 * max_tiles(n, S)) + 2 * align256(4 * (size_t)S) + 256; }
+// the int8 matrix-core kernel: its own tile list (PI8_ROWS positions per tile), digit planes and scales of W, column
+// flags, slot maxima / scales
+static size_t max_tiles_i8(int64_t n, int32_t S) { return (size_t)((n + PI8_ROWS - 1) / PI8_ROWS) + (size_t)S; }
+static size_t i8_bytes(int64_t n, int32_t S, int32_t n_samples) {
+  const size_t rows = (size_t)S * n_samples * 2;
+  return align256(16 * max_tiles_i8(n, S)) + 256 + align256(rows * ROWF * 4) + align256(rows * 4) + align256(4 * (size_t)S) + 3 * 256;
+}
 
 size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || S <= 0 || n_samples <= 0) return 0;
   return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + wd_bytes(S, n_samples) +
-         tile_bytes(num_envs, S) + align256(cub_group_bytes(num_envs));
+         tile_bytes(num_envs, S) + i8_bytes(num_envs, S, n_samples) + align256(cub_group_bytes(num_envs));
 }
 
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
@@ -383,6 +392,15 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   uint32_t *col_start = (uint32_t *)p; p += align256(4 * (size_t)env->tb.S);
   uint32_t *col_end = (uint32_t *)p;   p += align256(4 * (size_t)env->tb.S);
   uint32_t *n_tiles = (uint32_t *)p;   p += 256;
+  const size_t w_rows = (size_t)env->tb.S * env->tb.n_samples * 2;
+  uint4 *tiles_i8 = (uint4 *)p;        p += align256(16 * max_tiles_i8(env->n, env->tb.S));
+  uint32_t *n_tiles_i8 = (uint32_t *)p; p += 256;
+  uint32_t *wq = (uint32_t *)p;        p += align256(w_rows * ROWF * 4);
+  float *wscale = (float *)p;          p += align256(w_rows * 4);
+  uint32_t *colflag = (uint32_t *)p;   p += align256(4 * (size_t)env->tb.S);
+  uint32_t *xmax_bits = (uint32_t *)p; p += 256;  // [32] slot maxima (float bits), scanned once per table
+  uint32_t *bmax = (uint32_t *)p;      p += 256;
+  float *xs = (float *)p;              p += 256;  // [64] slot scales
   uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);  // sort keys, then the inverse permutation (stays in use)
   uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
@@ -397,10 +415,29 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   HIP_TRY(hipMemsetAsync(col_start, 0, 2 * align256(4 * (size_t)env->tb.S), s));
   hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k_out, col_start, col_end, env->n);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, col_start, col_end, env->tb.S, tiles, n_tiles);
+  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, col_start, col_end, env->tb.S, tiles, n_tiles, (uint32_t)PMV_THREADS);
+  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, col_start, col_end, env->tb.S, tiles_i8, n_tiles_i8, (uint32_t)PI8_ROWS);
   HIP_TRY(hipGetLastError());
   env->tiles = tiles;
   env->n_tiles = n_tiles;
+  // fixed-point operands of the int8 matrix-core kernel: slot maxima of the table (once per table and workspace), the
+  // episode's largest budget, slot scales, digit planes + epilogue scale of every coefficient row, column flags
+  if (env->xmax_ws != workspace) {
+    HIP_TRY(hipMemsetAsync(xmax_bits, 0, 256, s));
+    hipLaunchKernelGGL(k_pi8_slot_max, dim3(2048), dim3(256), 0, s, env->tb.X,
+                       (int64_t)env->tb.T * env->tb.S_w * env->tb.Y * (ROWF / 4), xmax_bits);
+    HIP_TRY(hipGetLastError());
+    env->xmax_ws = workspace;
+  }
+  HIP_TRY(hipMemsetAsync(bmax, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(colflag, 0, 4 * (size_t)env->tb.S, s));
+  hipLaunchKernelGGL(k_pi8_budget_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.stepc, env->n, bmax);
+  hipLaunchKernelGGL(k_pi8_scales, dim3(1), dim3(64), 0, s, xmax_bits, bmax, env->tb.T, xs);
+  hipLaunchKernelGGL(k_pi8_wq, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, env->tb.n_samples, wq, wscale, colflag);
+  HIP_TRY(hipGetLastError());
+  env->tiles_i8 = tiles_i8; env->n_tiles_i8 = n_tiles_i8; env->wq = wq; env->wscale = wscale; env->colflag = colflag;
+  env->xs = xs;
   // fp64 copy of the coefficient rows, scaled by -log2(e), for the lane = env form of the reward kernel
   const int64_t w_count = (int64_t)env->tb.S * env->tb.n_samples * 2 * ROWF;
   hipLaunchKernelGGL(k_pm_wd, dim3((unsigned)((w_count + 255) / 256)), dim3(256), 0, s,
@@ -429,7 +466,13 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
-  if (env->pm_kernel == W2A_PM_MATRIX_F64) {
+  if (env->pm_kernel == W2A_PM_MATRIX_I8) {
+    PmI8Args b;
+    b.p = a; b.tiles = env->tiles_i8; b.n_tiles = env->n_tiles_i8; b.wq = env->wq; b.wscale = env->wscale;
+    b.colflag = env->colflag; b.xs = env->xs;
+    const unsigned grid = (unsigned)((max_tiles_i8(env->n, env->tb.S) + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_posterior_mean_i8, dim3(grid), dim3(PI8_THREADS), 0, (hipStream_t)stream, b);
+  } else if (env->pm_kernel == W2A_PM_MATRIX_F64) {
     const unsigned grid = (unsigned)((env->n + PM_ROWS - 1) / PM_ROWS);
     if (env->w_tail_used) hipLaunchKernelGGL(k_posterior_mean<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_posterior_mean<7>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, a);
@@ -444,8 +487,8 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
 
 int w2a_set_posterior_kernel(w2a_env *env, int kernel) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_set_posterior_kernel: NULL handle");
-  if (kernel != W2A_PM_VECTOR && kernel != W2A_PM_MATRIX_F64)
-    return fail(W2A_ERR_ARG, "w2a_set_posterior_kernel: kernel must be W2A_PM_VECTOR or W2A_PM_MATRIX_F64");
+  if (kernel != W2A_PM_VECTOR && kernel != W2A_PM_MATRIX_F64 && kernel != W2A_PM_MATRIX_I8)
+    return fail(W2A_ERR_ARG, "w2a_set_posterior_kernel: kernel must be W2A_PM_VECTOR, W2A_PM_MATRIX_F64 or W2A_PM_MATRIX_I8");
   env->pm_kernel = kernel;
   return W2A_OK;
 }

@@ -442,15 +442,16 @@ __global__ void k_tile_bounds(const uint32_t *keys_sorted, uint32_t *col_start, 
   if (i == n - 1 || keys_sorted[i + 1] != k) col_end[k] = (uint32_t)i + 1u;
 }
 
-// one workgroup: tiles of every column in column order; tiles[j] = (first position, rows, column, 0)
+// one workgroup: tiles of <= tile_rows positions of every column in column order; tiles[j] = (first position, rows,
+// column, 0)
 __global__ __launch_bounds__(1024) void k_tile_list(const uint32_t *col_start, const uint32_t *col_end, int32_t S,
-                                                    uint4 *tiles, uint32_t *n_tiles) {
+                                                    uint4 *tiles, uint32_t *n_tiles, uint32_t tile_rows) {
   __shared__ uint32_t s_cnt[1024];
   const int tid = threadIdx.x;
   const int chunk = (S + 1023) / 1024;
   const int c0 = min(S, tid * chunk), c1 = min(S, c0 + chunk);
   uint32_t mine = 0;
-  for (int c = c0; c < c1; ++c) mine += (col_end[c] - col_start[c] + PMV_THREADS - 1) / PMV_THREADS;
+  for (int c = c0; c < c1; ++c) mine += (col_end[c] - col_start[c] + tile_rows - 1) / tile_rows;
   s_cnt[tid] = mine;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(1024) void k_tile_list(const uint32_t *col_start, c
   }
   uint32_t j = s_cnt[tid] - mine;
   for (int c = c0; c < c1; ++c)
-    for (uint32_t st = col_start[c]; st < col_end[c]; st += PMV_THREADS)
-      tiles[j++] = make_uint4(st, min((uint32_t)PMV_THREADS, col_end[c] - st), (uint32_t)c, 0u);
+    for (uint32_t st = col_start[c]; st < col_end[c]; st += tile_rows)
+      tiles[j++] = make_uint4(st, min(tile_rows, col_end[c] - st), (uint32_t)c, 0u);
   if (tid == 1023) *n_tiles = s_cnt[1023];
 }
 

@@ -77,8 +77,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          reward form -- one grouped contraction per step (csrc/w2a_posterior.hip.h).
                          Needs lock-step / disabled autoreset and faithful semantics.
     pm_kernel            which kernel computes that contraction: "vector" (fp64 FMAs on the vector ALU with
-                         DPP-broadcast coefficients), "matrix" (fp64 matrix cores, v_mfma_f64_16x16x4_f64), or "auto"
-                         (default): both are timed once on this env's own batch after the first reset and the faster
+                         DPP-broadcast coefficients), "matrix" (fp64 matrix cores, v_mfma_f64_16x16x4_f64),
+                         "matrix_i8" (int8 matrix cores on exact fixed-point digits of both operands,
+                         v_mfma_i32_16x16x64_i8 with int32 accumulation; csrc/w2a_posterior_i8.hip.h), or "auto"
+                         (default): all are timed once on this env's own batch after the first reset and the fastest
                          one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why).
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
                          64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
@@ -117,7 +119,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         step_kernel: Literal["auto", "classic", "wide"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         rollout_order: bool = True,
-        pm_kernel: Literal["auto", "vector", "matrix"] = "auto",
+        pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "auto",
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -164,7 +166,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if reward_mode == "posterior_mean" and (self.fixes or step_kernel == "classic"):
             raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
-        if pm_kernel not in ("auto", "vector", "matrix"):
+        if pm_kernel not in ("auto", "vector", "matrix", "matrix_i8"):
             raise ValueError(f"pm_kernel {pm_kernel!r}")
         self.pm_kernel = pm_kernel
         self.pm_kernel_choice = None if pm_kernel == "auto" else pm_kernel  # decided after the first reset
