@@ -53,10 +53,12 @@ WORKLOADS = {
 }
 
 
-def compulsory_bytes(n_obs: int, write_obs: bool) -> dict:
-    """Bytes per env-step that must cross HBM for the row-gather step kernel."""
-    rd = {"action": 4, "hot3": 12, "stepc": 12}
-    wr = {"reward": 4, "done": 1, "hot3": 12}
+def compulsory_bytes(n_obs: int, write_obs: bool, packed: bool = False) -> dict:
+    """Bytes per env-step that must cross HBM for the row-gather step kernel. `packed`: the batch is in
+    lock step and the kernel streams the 16-B packed mirror of the per-env state (8 + 8 B in, 8 B out) instead of the
+    canonical words (12 + 12 in, 12 out)."""
+    rd = {"action": 4, "pk_hot": 8, "pk_c": 8} if packed else {"action": 4, "hot3": 12, "stepc": 12}
+    wr = {"reward": 4, "done": 1, "pk_hot": 8} if packed else {"reward": 4, "done": 1, "hot3": 12}
     if write_obs:
         wr["obs"] = 4 * n_obs
     return {"read": rd, "write": wr, "total": sum(rd.values()) + sum(wr.values())}
@@ -82,7 +84,8 @@ def parse(argv=None):
                         "small batches); the timed region still runs exactly --steps steps")
     p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"],
                    help="sorted = opt-in relabelling of envs by table row after each reset (same episode multiset)")
-    p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
+    p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide", "unpacked"],
+                   help="unpacked = auto without the packed lock-step mirror of the per-env state (A/B)")
     p.add_argument("--launch-timeout", type=float, default=1500.0,
                    help="--gpus N self-launcher: seconds after which still-running ranks are terminated")
     p.add_argument("--fail-rank", type=int, default=-1,
@@ -642,15 +645,16 @@ def main():
                 env.step(pool[0])  # finish this episode: the measurement must not contain a reset kernel
         kms, _ = timed_steps(env, pool, k_steps, torch)
         kernel_us = kms * 1e3 / k_steps
+    packed = env.packed_state  # the form the step kernel streamed in the measured launches
 
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
-        cb = compulsory_bytes(ct.n_obs, not args.no_obs)
+        cb = compulsory_bytes(ct.n_obs, not args.no_obs, packed)
         achieved = cb["total"] * n / per_launch_s / 1e9
         variant = env.step_kernel_name
-        kname = f"{variant}<obs={not args.no_obs}>" + (" (in-kernel autoreset)" if env._dev_auto else
-                                                         " + k_reset once per episode")
+        kname = f"{variant}<obs={not args.no_obs}{', packed lock-step state' if packed else ''}>" + (
+            " (in-kernel autoreset)" if env._dev_auto else " + k_reset once per episode")
         # fabric traffic from the PMC passes, only if collected on these very kernel sources
         src_sha = wbuild.source_sha()
         traffic = traffic_note = None
@@ -668,10 +672,12 @@ def main():
         # profiles/, 1 048 576 envs): kernel time / probe time says how close the kernel is to what the chip delivers
         probe = None
         try:
-            pc = json.load(open(os.path.join(ROOT, "profiles", "probe_ceiling.json"))).get(args.workload)
+            pc = json.load(open(os.path.join(ROOT, "profiles", "probe_ceiling.json")))["packed" if packed else "unpacked"]
+            pc = pc.get(args.workload)
             if pc and n == 1048576 and not args.no_obs:
                 probe = {"probe_us": pc["us"], "kernel_over_probe": per_launch_s * 1e6 / pc["us"],
-                         "source": "profiles/r02/fabric_probe.log (tools/fabric_probe.hip, random data)"}
+                         "source": "profiles/r03/fabric_probe.log (tools/fabric_probe.hip, random data, "
+                                   + ("packed" if packed else "unpacked") + " state streams)"}
         except Exception:  # noqa: BLE001
             probe = None
         out = {
@@ -683,7 +689,8 @@ def main():
                        "episode_days": T, "n_samples": ct.n_samples, "obs": not args.no_obs,
                        "policy": "Bernoulli(0.1) actions from a device RNG, table budgets",
                        "seed_mode": "device", "autoreset": "same_step", "reward_path": "gather",
-                       "step_kernel": variant, "episode_order": args.episode_order, "hipgraph_steps": args.graph,
+                       "step_kernel": variant, "packed_lockstep_state": packed, "episode_order": args.episode_order,
+                       "hipgraph_steps": args.graph,
                        "collective": "all_gather_into_tensor(f32[num_envs_per_gpu]) per episode, overlapped with the next "
                                      "episode's steps" if world > 1 else "none",
                        "single_gpu_reference": f"python bench.py --gpus 1 --workload {args.workload}"
@@ -706,6 +713,8 @@ def main():
                          "traffic_note": traffic_note, "kernel_src_sha": src_sha,
                          "probe_ceiling": probe,
                          "frac_of_measured_copy_bw": achieved / 6290.0,
+                         "frac_with_unpacked_161B_model": compulsory_bytes(ct.n_obs, not args.no_obs)["total"] * n
+                         / per_launch_s / 1e9 / HBM_PEAK_GBS,
                          "survey_8d_model": {"bytes_per_env_step": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"],
                                              "gbs": SURVEY_8D_BYTES["no_obs" if args.no_obs else "obs"] * n
                                              / per_launch_s / 1e9,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 10
+#define W2A_ABI_VERSION 11
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -56,6 +56,8 @@ enum {
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
   W2A_STEP_WIDE = 32,     /* force the 64-envs-per-wave kernel for small batches too (by default it serves batches of
                              >= 131 072 envs, the 4-lanes-per-env kernel smaller ones: the faster one on MI355X) */
+  W2A_STEP_UNPACKED = 128, /* do not use the lock-step mirror of the per-env state (below; same results; for A/B
+                             measurements and tests) */
   W2A_STEP_SKIP_FINISHED = 64, /* with W2A_STEP_REWARD_GIVEN: envs whose episode is over are left untouched (reward
                              written as 0, done 1, state / return / observation unchanged, no status bit): policy
                              loops over batches that are not in lock step */
@@ -120,7 +122,15 @@ typedef struct w2a_state_view {
 int w2a_abi_version(void);
 const char *w2a_last_error(void);
 
-/* Bytes of caller-owned device memory one handle needs for `num_envs` envs (256-B aligned). */
+/* Bytes of caller-owned device memory one handle needs for `num_envs` envs (256-B aligned): 40 B per env of
+ * canonical state (episode record, read-only step constants, counters + return) and a 16-B lock-step mirror. While the
+ * handle knows the batch to be in lock step -- every env reset together by an unmasked reset, one episode length for
+ * every (county, year), plain steps since -- the day, the episode length and the `finished` bit are the same for
+ * every env and travel as kernel arguments; the 64-envs-per-wave step kernel then streams 8 + 8 B of packed state per
+ * env in and 8 B out instead of 12 + 12 and 12 (needs T <= 255, S < 65536, n_samples <= 1024, S_w * Y < 2^22 and
+ * budgets <= 65535; anything else uses the canonical arrays). The library converts between the two forms by itself
+ * whenever an entry point needs the other one; a caller that rewrites the state buffer behind the library's back
+ * (checkpoint restore) must call w2a_invalidate. */
 size_t w2a_state_bytes(int64_t num_envs);
 
 /* Replaces HeatAlertEnv.__init__ (env.py:20-105) for `num_envs` envs whose global ids are
@@ -277,6 +287,16 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
 
 /* Decode the packed state into the caller's arrays (see w2a_state_view). */
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
+
+/* What the handle knows (host-side bookkeeping, no device work): the day every env is on if the batch is known to be in
+ * lock step (-1 otherwise); whether tables and budgets allow the lock-step mirror at all; which of the two forms of
+ * the step state is current. */
+enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3 };
+int w2a_query(w2a_env *env, int what);
+
+/* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived
+ * form (lock-step mirror, column grouping, what is known about days and budgets). */
+int w2a_invalidate(w2a_env *env);
 
 /* Synchronise `stream`, read and clear the device status word (host int out). */
 int w2a_read_status(w2a_env *env, int32_t *status_out, void *stream);

@@ -32,11 +32,11 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 10
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 11
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
-    assert b >= 256 + 40 * n and b % 256 == 0
+    assert b >= 256 + 56 * n and b % 256 == 0
     # NULL / bad arguments are rejected on the host with a message, nothing is launched
     h = C.c_void_p()
     assert lib.w2a_create(None, 10, 0, None, 0, None, C.byref(h)) == -1

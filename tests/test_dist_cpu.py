@@ -151,3 +151,4 @@ def test_bench_defaults_follow_baseline_configs():
     assert b.WORKLOADS["configs4"][:3] == ("nn_full_medicare_all", 1048576, False)
     cb = b.compulsory_bytes(29, True)
     assert cb["total"] == 161 and b.compulsory_bytes(29, False)["total"] == 45
+    assert b.compulsory_bytes(29, True, packed=True)["total"] == 149  # 8 + 8 + 4 in, 8 + 4 + 1 + 116 out

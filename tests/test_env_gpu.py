@@ -266,6 +266,80 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     old.close()
 
 
+def test_packed_lockstep_state_equals_canonical_state(dev):
+    """While a batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env state
+    (day / episode length / finished bit as kernel arguments) instead of the 24-B canonical words. Same arithmetic, so
+    everything must be BIT-identical to the unpacked kernel: observations, rewards, done, returns, decoded state --
+    through a whole episode, the host-driven lock-step autoreset into the next one, state() read-backs (packed ->
+    canonical conversion mid-episode), a rollout() in between (leaves lock step: canonical form until the next reset),
+    a masked reset, and a checkpoint restore. The handle's bookkeeping is checked through w2a_query."""
+    from weather2alert_amd import HeatAlertVecEnv, _ffi
+
+    sd = synth.make_synth("linear", n_fips=40, years=[2006, 2007, 2008], n_samples=10, seed=51, extra_confounder_fips=4)
+    ct = tables.compile_from_synth(sd)
+    n = 131072 + 77  # from 131 072 envs on w2a_step picks the 64-envs-per-wave kernel by itself
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, step_kernel="auto")
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, step_kernel="unpacked")
+    q = lambda e, what: e._lib.w2a_query(e._h, what)  # noqa: E731
+    oa, _ = A.reset(seed=12)
+    ob, _ = B.reset(seed=12)
+    assert torch.equal(oa, ob) and q(A, _ffi.Q_PACKED_ELIGIBLE) == 1 and q(A, _ffi.Q_LOCKSTEP_DAY) == 0
+    assert not A.packed_state and not B.packed_state
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def both(act):
+        ra, rb = A.step(act), B.step(act)
+        for x, y in zip(ra[:3], rb[:3]):
+            assert torch.equal(x, y)
+
+    def same_state():
+        sa, sb = A.state(), B.state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+    for t in range(153 + 40):  # one whole episode, the lock-step autoreset, 40 days of the next
+        both((torch.rand(n, device=dev, generator=g) < 0.15).to(torch.int32))
+        day = (t + 1) % 153
+        assert A.packed_state == (day != 0) and not B.packed_state, t  # the reset after the terminal step is canonical
+        assert q(A, _ffi.Q_LOCKSTEP_DAY) == day
+        if t % 37 == 5:
+            same_state()  # read-back converts to the canonical form; the packed one stays valid
+            assert q(A, _ffi.Q_PACKED_CURRENT) == 1 and q(A, _ffi.Q_CANONICAL_CURRENT) == 1
+    assert torch.equal(A._final_return, B._final_return)
+    # a rollout leaves lock step as far as the handle knows: canonical kernel from here to the next full reset
+    pol = dict(kind="bernoulli", p=0.2, seed=4)
+    ra, rb = A.rollout(pol, n_steps=10), B.rollout(pol, n_steps=10)
+    assert torch.equal(ra["alerts"], rb["alerts"]) and torch.equal(ra["return"], rb["return"])
+    both(torch.ones(n, dtype=torch.int32, device=dev))
+    assert not A.packed_state and q(A, _ffi.Q_LOCKSTEP_DAY) == -1
+    same_state()
+    A.reset(seed=13)
+    B.reset(seed=13)
+    for t in range(20):
+        both((torch.rand(n, device=dev, generator=g) < 0.3).to(torch.int32))
+    assert A.packed_state
+    # checkpoint in the packed form, restore into a fresh env, continue: identical to the uninterrupted run
+    ck = A.state_dict()
+    C2 = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, step_kernel="auto")
+    C2.reset(seed=99)
+    C2.load_state_dict(ck)
+    for t in range(15):
+        act = (torch.rand(n, device=dev, generator=g) < 0.3).to(torch.int32)
+        both(act)
+        rc = C2.step(act)
+        assert torch.equal(rc[0], A._obs) and torch.equal(rc[1], A._reward)
+    # a masked reset ends lock step
+    m = np.arange(n) % 3 == 0
+    A.reset(seed=14, options={"mask": m})
+    B.reset(seed=14, options={"mask": m})
+    both(torch.zeros(n, dtype=torch.int32, device=dev))
+    assert not A.packed_state
+    same_state()
+    assert A.check_status() == 0 and B.check_status() == 0
+    for e in (A, B, C2):
+        e.close()
+
+
 def test_removed_table_path_is_refused(dev, mini):
     from weather2alert_amd import HeatAlertVecEnv
 

@@ -42,13 +42,28 @@ def collect(tag, out, rnd):
         if line:
             open(os.path.join(out, f"bench_under_rocprof_{tag}.json"), "w").write(line[-1] + "\n")
     # 2. PMC passes (tools/pmc_probe.py): per-kernel means
-    pmc = {}
+    # Every pass records the hash of the kernel sources it ran on (<pass>_<tag>.probe.json, written next to its
+    # summary by tools/gpu_session.sh). Passes are merged only when they ran on the SAME sources as the newest one:
+    # a summary left in gpurun_out/ by an older build would otherwise smuggle kernels that no longer exist into
+    # pmc_<tag>.json.
+    probe = {}
+    pj = os.path.join(GO, f"pmc_probe_{tag}.json")
+    if os.path.exists(pj):
+        probe = json.load(open(pj))
+    pmc, skipped = {}, []
     for name in ("prof_fetch", "prof_write", "prof_tcc", "prof_sq", "prof_sq2", "prof_mfma"):
         fp = os.path.join(GO, f"{name}_{tag}.summary.json")
-        if os.path.exists(fp):
-            for k, v in json.load(open(fp)).items():
-                if any(x in k for x in KEEP):
-                    pmc.setdefault(k, {}).update({kk: vv for kk, vv in v.items() if not kk.endswith("_n")})
+        if not os.path.exists(fp):
+            continue
+        pp = os.path.join(GO, f"{name}_{tag}.probe.json")
+        sha = json.load(open(pp)).get("src_sha") if os.path.exists(pp) else None
+        if sha != probe.get("src_sha"):
+            skipped.append({"pass": name, "src_sha": sha})
+            print(f"{tag}: pass {name} ran on kernel sources {sha}, not {probe.get('src_sha')}: left out")
+            continue
+        for k, v in json.load(open(fp)).items():
+            if any(x in k for x in KEEP):
+                pmc.setdefault(k, {}).update({kk: vv for kk, vv in v.items() if not kk.endswith("_n")})
     # calibration from the raw CSVs: the 1 GiB copy launches of the probe
     calib = {}
     for name, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
@@ -62,12 +77,9 @@ def collect(tag, out, rnd):
             vals = [v for (d, k), v in per.items() if "copyBuffer" in k and v > 1e5]
             if vals:
                 calib[f"copy_1GiB_{ctr}_KB"] = sum(vals) / len(vals)
-    probe = {}
-    pj = os.path.join(GO, f"pmc_probe_{tag}.json")
-    if os.path.exists(pj):
-        probe = json.load(open(pj))
-    res = {"tag": tag, "probe": probe, "pmc": pmc, "calibration": calib}
-    main = "k_posterior_mean" if tag.endswith("_pm") else probe.get("step_kernel", "k_step64")
+    res = {"tag": tag, "probe": probe, "pmc": pmc, "calibration": calib, "passes_left_out": skipped}
+    is_pm = "_pm" in tag
+    main = "k_posterior_mean" if is_pm else probe.get("step_kernel", "k_step64")
     kk = [k for k in pmc if main in k and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
     if kk:
         e = pmc[kk[0]]
@@ -79,7 +91,7 @@ def collect(tag, out, rnd):
         res["traffic"] = {"kernel": kk[0], "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                           "bytes_per_launch": rd + wr, "read_correction": rd_corr, "write_correction": wr_corr,
                           "kernel_avg_us": e.get("avg_us")}
-        if not tag.endswith("_pm") and probe.get("src_sha"):
+        if not is_pm and probe.get("src_sha"):
             tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
             cur = json.load(open(tl)) if os.path.exists(tl) else {}
             cur = {k: v for k, v in cur.items() if isinstance(v, dict)}
@@ -101,7 +113,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     for tag in a.tags:
         collect(tag, out, a.round)
-    logs = ["bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
+    logs = ["toolchain.txt", "pm_i8_variants.log", "bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
             "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log", "pm_trace.log",
             "pm_variants.log", "pm_tests_matrix.log", "pm_rollout.log", "mfma_overlap_probe.log"]
     for f in logs:

@@ -13,7 +13,13 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifdef PROBE_PACKED  // what-if: the per-env state streams as 8 + 8 B in and 8 B out instead of 12 + 12 in, 12 out
+struct u3 { uint32_t b, c; uint32_t a_() const { return 0; } };
+#define U3_A(v) 0u
+#else
 struct u3 { uint32_t a, b, c; };
+#define U3_A(v) (v).a
+#endif
 
 template <bool STREAM, bool GATHER>
 __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc, const int32_t *act, u3 *hot_out,
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   if (env0 >= n) return;
   const uint32_t e = (uint32_t)(env0 + lane);
   float acc = 0.0f;
-  u3 h = {0, 0, 0}, c = {0, 0, 0};
+  u3 h = {}, c = {};
   int32_t a = 0;
   if (STREAM) { h = hot[e]; c = stepc[e]; a = act[e]; }
   const int p = lane & 7, g = lane >> 3;
@@ -105,7 +111,11 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   // lane = env outputs
   acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
   if (STREAM) {
+#ifdef PROBE_PACKED
+    h.b += (uint32_t)a; h.c = __float_as_uint(acc + (float)c.b);
+#else
     h.a += (uint32_t)a; h.c = __float_as_uint(acc + __uint_as_float(c.a) + (float)c.b);
+#endif
     hot_out[e] = h;
     reward[e] = acc;
     done[e] = (uint8_t)(h.b & 1u);
@@ -118,11 +128,11 @@ int main() {
   const int64_t n = 1 << 20;
   const int S = 74600, R = 8206;  // coefficient rows (x 256 B) and day-slice rows (x 128 B)
   u3 *hot, *stepc, *hot_out; int32_t *act; float *reward, *obs; uint8_t *done; float4 *W, *X; uint32_t *wrow, *xrow;
-  CHECK(hipMalloc(&hot, n * 12)); CHECK(hipMalloc(&stepc, n * 12)); CHECK(hipMalloc(&hot_out, n * 12));
+  CHECK(hipMalloc(&hot, n * sizeof(u3))); CHECK(hipMalloc(&stepc, n * sizeof(u3))); CHECK(hipMalloc(&hot_out, n * sizeof(u3)));
   CHECK(hipMalloc(&act, n * 4)); CHECK(hipMalloc(&reward, n * 4)); CHECK(hipMalloc(&done, n));
   CHECK(hipMalloc(&obs, n * 29 * 4)); CHECK(hipMalloc(&W, (size_t)S * 256)); CHECK(hipMalloc(&X, (size_t)R * 128 * 153));
   CHECK(hipMalloc(&wrow, n * 4)); CHECK(hipMalloc(&xrow, n * 4));
-  CHECK(hipMemset(hot, 0, n * 12)); CHECK(hipMemset(stepc, 0, n * 12)); CHECK(hipMemset(act, 0, n * 4));
+  CHECK(hipMemset(hot, 0, n * sizeof(u3))); CHECK(hipMemset(stepc, 0, n * sizeof(u3))); CHECK(hipMemset(act, 0, n * 4));
   CHECK(hipMemset(W, 0, (size_t)S * 256)); CHECK(hipMemset(X, 0, (size_t)R * 128 * 153));
 #ifdef PROBE_RANDOM_DATA  // random table values instead of zeros (arithmetic on zeros draws less power: clocks differ)
   {
@@ -146,14 +156,14 @@ int main() {
     if (mode == 1) for (int64_t i = 0; i < n; ++i) hw[i] %= 25000;
     CHECK(hipMemcpy(wrow, hw, n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(xrow, hx, n * 4, hipMemcpyHostToDevice));
     {
-      u3 *hs = (u3 *)malloc(n * 12);
-      for (int64_t i = 0; i < n; ++i) { hs[i].a = 0; hs[i].b = hx[i]; hs[i].c = hw[i]; }
-      CHECK(hipMemcpy(stepc, hs, n * 12, hipMemcpyHostToDevice));
+      u3 *hs = (u3 *)malloc(n * sizeof(u3));
+      for (int64_t i = 0; i < n; ++i) { hs[i] = u3{}; hs[i].b = hx[i]; hs[i].c = hw[i]; }
+      CHECK(hipMemcpy(stepc, hs, n * sizeof(u3), hipMemcpyHostToDevice));
       free(hs);
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const dim3 grid((unsigned)(n / 256)), block(256);
-    const char *names[3] = {"stream only (161 B/env compulsory)", "gather only (2 x 128-B lines/env)", "stream + gather"};
+    const char *names[3] = {sizeof(u3) == 8 ? "stream only (149 B/env: 8 + 8 + 4 in, 8 + 121 out)" : "stream only (161 B/env compulsory)", "gather only (2 x 128-B lines/env)", "stream + gather"};
     for (int k = 0; k < 3; ++k) {
       float best = 1e9f;
       for (int rep = 0; rep < 3; ++rep) {

@@ -4,6 +4,10 @@ set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -m weather2alert_amd.build > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+# toolchain of this box, kept with the evidence (tools/collect_profiles.py copies it)
+{ echo "# hipcc --version"; hipcc --version 2>&1; echo "# /opt/rocm/.info/version"; cat /opt/rocm/.info/version 2>/dev/null;
+  echo "# rocminfo (gfx, CUs)"; rocminfo 2>/dev/null | grep -E "Marketing Name|Name: +gfx|Compute Unit" | sort | uniq -c | head -8;
+  echo "# torch"; python -c "import torch; print(torch.__version__, torch.version.hip)"; } > gpurun_out/toolchain.txt 2>&1
 for step in "$@"; do
   case $step in
     tests)
@@ -55,12 +59,16 @@ for step in "$@"; do
       IFS=: read -r _ w order <<< "$step"
       tag=$w; extra=""; bextra=""
       if [ "$order" == "sorted" ]; then tag=${w}_sorted; extra="--episode-order sorted"; bextra="--episode-order sorted"; fi
-      if [ "$order" == "pm" ]; then
-        # posterior-mean reward kernel: issue counters (the kernel trace of bench.py already lists k_posterior_mean_v)
-        tag=${w}_pm
-        for grp in "mfma:SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+      if [ "${order%%_*}" == "pm" ]; then
+        # prof:<workload>:pm_<vector|matrix|matrix_i8>: issue counters (MFMA instructions and busy cycles, VALU, waits, LDS)
+        # and fabric bytes of one posterior-mean reward kernel of the library, selected at run time
+        pmk=${order#pm_}; [ "$pmk" == "pm" ] && pmk=vector
+        tag=${w}_pm_$pmk
+        rm -rf gpurun_out/prof_*_$tag gpurun_out/prof_*_$tag.summary.json gpurun_out/prof_*_$tag.summary.txt gpurun_out/prof_*_$tag.probe.json
+        for grp in "mfma:SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS" "sq2:SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
           name=${grp%%:*}; ctrs=${grp#*:}
-          timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $PWD/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w --reward-mode posterior_mean --steps 12 > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
+          timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $PWD/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w --reward-mode posterior_mean --pm-kernel $pmk --steps 12 > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
+          cp gpurun_out/pmc_probe_$tag.json gpurun_out/prof_${name}_$tag.probe.json
           python tools/rocprof_summary.py gpurun_out/prof_${name}_$tag --json gpurun_out/prof_${name}_$tag.summary.json > gpurun_out/prof_${name}_$tag.summary.txt 2>&1
           find gpurun_out/prof_${name}_$tag -name "*.csv" -size +2M -delete
           grep k_posterior gpurun_out/prof_${name}_$tag.summary.txt | cut -c1-700
@@ -68,11 +76,12 @@ for step in "$@"; do
         continue
       fi
       R=$PWD
-      rm -rf gpurun_out/prof_*_$tag
+      rm -rf gpurun_out/prof_*_$tag gpurun_out/prof_*_$tag.summary.json gpurun_out/prof_*_$tag.summary.txt gpurun_out/prof_*_$tag.probe.json
       timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt_$tag -- python3 bench.py --workload $w $bextra --no-cpu-baseline --no-extras > gpurun_out/prof_kt_$tag.log 2>&1; echo "prof_kt $tag exit $?"
       for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "sq2:SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
         name=${grp%%:*}; ctrs=${grp#*:}
         timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/prof_${name}_$tag -- python3 tools/pmc_probe.py --workload $w $extra > gpurun_out/prof_${name}_$tag.log 2>&1; echo "prof_$name $tag exit $?"
+        cp gpurun_out/pmc_probe_$tag.json gpurun_out/prof_${name}_$tag.probe.json  # which kernel sources this pass ran on
       done
       for d in prof_kt prof_fetch prof_write prof_tcc prof_sq prof_sq2; do
         python tools/rocprof_summary.py gpurun_out/${d}_$tag --json gpurun_out/${d}_$tag.summary.json > gpurun_out/${d}_$tag.summary.txt 2>&1

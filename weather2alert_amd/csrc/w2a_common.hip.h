@@ -64,7 +64,23 @@ struct StateArrays {
   uint4 *cold;
   u3 *hot3;
   u3 *stepc;
+  // lock-step mirror of hot3 / stepc, 8 + 8 B per env (k_step64's packed variant streams 20 B in and 8 B out per
+  // env-step instead of 28 and 12). In lock step the day t, the episode length and -- until the terminal step -- the
+  // `finished` bit are the same for every env and travel as kernel arguments:
+  //   pk_hot.x: used[0:8) streak[8:16) hist14[16:30) finished[30]      pk_hot.y: episode return (f32 bits)
+  //   pk_c.x:   budget[0:16) coef_col[16:32)                            pk_c.y:   ep_row[0:22) sample[22:32)
+  // (last_actual = hist14 & 1; at_budget is derived). Valid for T <= 255, S < 65536, n_samples <= 1024,
+  // S_w * Y < 2^22, budgets <= 65535 -- checked on the host, which also tracks which of the two forms is current.
+  uint2 *pk_hot;
+  uint2 *pk_c;
 };
+#define PK_USED(w) ((w) & 255u)
+#define PK_STREAK(w) (((w) >> 8) & 255u)
+#define PK_HIST(w) (((w) >> 16) & 0x3FFFu)
+#define PK_FIN(w) (((w) >> 30) & 1u)
+__device__ __forceinline__ uint32_t pk_pack_hot(uint32_t used, uint32_t streak, uint32_t hist, uint32_t fin) {
+  return (used & 255u) | ((streak & 255u) << 8) | ((hist & 0x3FFFu) << 16) | (fin << 30);
+}
 // per-step view: hot complete, cold.x/.y valid (cold.z/.w = 0: load_cold() when the sticky budget / episode
 // number are needed)
 __device__ __forceinline__ void load_step_state(const StateArrays &s, uint32_t e, uint4 &cold, uint4 &hot) {
@@ -167,6 +183,11 @@ struct w2a_env {
   const void *xmax_ws;   // workspace whose slot maxima (once-per-table scan) are valid
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
+  // which form of the per-env step state is current (see StateArrays): the canonical arrays, the lock-step mirror,
+  // or both; uni_t = the day every env is on when the batch is known to be in lock step (-1: not known)
+  int pk_valid, canon_valid, pk_static_ok;
+  int32_t uni_t, uni_nd, pk_t, b0_max;
+  int64_t budget_bound;  // no env's budget exceeds this (INT64_MAX: unknown)
   int pm_kernel;         // W2A_PM_* : which posterior-mean reward kernel w2a_posterior_mean_reward launches
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };

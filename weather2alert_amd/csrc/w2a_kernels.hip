@@ -110,7 +110,32 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
   const size_t n = (size_t)num_envs;
-  return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n);
+  return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n) + 2 * align256(8 * n);
+}
+
+// ---- which form of the step state is current (StateArrays::pk_hot / pk_c, w2a_common.hip.h) -------------------------
+static void ensure_canonical(w2a_env *env, hipStream_t s) {
+  if (env->canon_valid) return;
+  hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, env->pk_t,
+                     env->uni_nd);
+  env->canon_valid = 1;
+}
+// the canonical arrays are about to be modified by something that does not maintain the lock-step mirror
+static void canonical_modified(w2a_env *env, bool keeps_lockstep = false) {
+  env->pk_valid = 0;
+  if (!keeps_lockstep) env->uni_t = -1;
+}
+static void note_budgets(w2a_env *env, int64_t cand, int sample_mode, int sticky) {
+  if (cand < 0 || (sample_mode == W2A_BUDGET_CENTERED && sticky)) { env->budget_bound = INT64_MAX; return; }  // unknown /
+  if (sample_mode == W2A_BUDGET_CENTERED) cand = cand + cand / 2 + 1;        // a sticky centred budget is a random walk
+  if (cand > env->budget_bound) env->budget_bound = cand;
+}
+__global__ void k_table_scan(const int32_t *n_days, const int32_t *B0, int32_t rows, int32_t *out) {  // out: min nd, max nd, max B0
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  atomicMin(&out[0], n_days[i]);
+  atomicMax(&out[1], n_days[i]);
+  atomicMax(&out[2], B0[i]);
 }
 
 int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *state, size_t state_bytes,
@@ -166,6 +191,10 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.cold = reinterpret_cast<uint4 *>((char *)state + HDR_BYTES);
   h->st.hot3 = reinterpret_cast<u3 *>((char *)h->st.cold + align256(16 * (size_t)num_envs));
   h->st.stepc = reinterpret_cast<u3 *>((char *)h->st.hot3 + align256(12 * (size_t)num_envs));
+  h->st.pk_hot = reinterpret_cast<uint2 *>((char *)h->st.stepc + align256(12 * (size_t)num_envs));
+  h->st.pk_c = reinterpret_cast<uint2 *>((char *)h->st.pk_hot + align256(8 * (size_t)num_envs));
+  h->pk_valid = 0; h->canon_valid = 1; h->uni_t = -1; h->uni_nd = -1; h->pk_t = 0; h->b0_max = 0; h->budget_bound = 0;
+  h->pk_static_ok = (t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22)) ? 1 : 0;
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
@@ -190,6 +219,17 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   if (e3 == hipSuccess && e4 == hipSuccess) e3 = hipMemcpy(&tail_used, scan_flag, sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e3 != hipSuccess || e4 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernels failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : e4)); }
   h->w_tail_used = tail_used;
+  {  // one episode length for every (county, year)? largest default budget? (eligibility of the lock-step mirror)
+    int32_t scan[3] = {0x7FFFFFFF, 0, 0};
+    int32_t *d_scan = reinterpret_cast<int32_t *>(state) + ROWF + 1;  // header words 33..35
+    hipError_t e5 = hipMemcpy(d_scan, scan, sizeof(scan), hipMemcpyHostToDevice);
+    const int32_t rows = t->S_w * t->Y;
+    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, t->n_days, t->B0, rows, d_scan);
+    if (e5 == hipSuccess) e5 = hipMemcpy(scan, d_scan, sizeof(scan), hipMemcpyDeviceToHost);
+    if (e5 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: table scan failed: %s", hipGetErrorString(e5)); }
+    h->uni_nd = (scan[0] == scan[1] && scan[0] > 0) ? scan[0] : -1;
+    h->b0_max = scan[2];
+  }
   *out = h;
   return W2A_OK;
 }
@@ -204,6 +244,14 @@ static unsigned grid_for(int64_t n) {
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   if (a.from_tuples != 2) env->perm_valid = 0;  // new episode tuples: the column grouping is stale
+  // a full reset rewrites every env's canonical words (it reads only `cold`, which is never stale); a masked reset
+  // and w2a_observe read the rest as well
+  if (a.mask || a.from_tuples == 2) ensure_canonical(env, (hipStream_t)stream);
+  if (a.from_tuples != 2) {
+    env->canon_valid = 1;
+    canonical_modified(env);
+    if (!a.mask && env->uni_nd > 0) env->uni_t = 0;  // every env on day 0 of an episode of the one length there is
+  }
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
@@ -219,6 +267,7 @@ int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, cons
   memset(&a, 0, sizeof(a));
   a.county_w = county_w; a.year_i = year_i; a.coef_col = coef_col; a.sample = sample; a.budget = budget;
   a.mask = mask; a.obs = obs; a.from_tuples = 1;
+  note_budgets(env, budget ? -1 : env->b0_max, W2A_BUDGET_FIXED, 0);  // caller's budgets live in device memory: unknown
   return launch_reset(env, a, stream);
 }
 
@@ -240,6 +289,7 @@ int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augm
   int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   a.mask = mask; a.obs = obs; a.from_tuples = 0; a.restart = restart_episodes ? 1 : 0;
+  note_budgets(env, budget_kw >= 0 ? budget_kw : env->b0_max, sample_budget_mode, sticky);
   return launch_reset(env, a, stream);
 }
 
@@ -249,6 +299,7 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
   int rc = fill_cfg(env, env->autoreset, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   env->has_autoreset = 1;
+  note_budgets(env, budget_kw >= 0 ? budget_kw : env->b0_max, sample_budget_mode, sticky);
   return W2A_OK;
 }
 
@@ -282,12 +333,35 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
+  // the day every env is on after this call, if the batch is (still) known to be in lock step: a plain step moves all
+  // of them to the next day; the terminal step, an in-kernel autoreset or unknown state ends the knowledge
+  const int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
   if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
     const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
     const int64_t tiles = (env->n + per_wg - 1) / per_wg;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
+    // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
+    const bool packed = !given && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
+                        env->budget_bound <= 65535;
+    if (packed) {
+      if (!env->pk_valid) {  // entering the packed form (once per episode): the canonical arrays are current
+        hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);
+        env->pk_valid = 1;
+      }
+      a.uni_t = env->uni_t; a.uni_nd = env->uni_nd;
+      if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
+      else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
+      HIP_TRY(hipGetLastError());
+      env->canon_valid = 0;
+      env->pk_t = uni_next >= 0 ? uni_next : env->uni_t;  // the terminal step leaves t where it is (env.py:256-259)
+      env->uni_t = uni_next;
+      return W2A_OK;
+    }
+    ensure_canonical(env, s);
+    canonical_modified(env, true);
+    env->uni_t = uni_next;
     if (given) {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
@@ -299,6 +373,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     return W2A_OK;
   }
 #endif
+  ensure_canonical(env, s);
+  canonical_modified(env, true);
+  env->uni_t = uni_next;
 #define W2A_LAUNCH(AR, OB) \
   do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, true>), grid, block, 0, s, a); \
        else hipLaunchKernelGGL((k_step<AR, OB, false>), grid, block, 0, s, a); } while (0)
@@ -340,6 +417,8 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   size_t cub_bytes = cub_sort_bytes(env->n);
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
+  ensure_canonical(env, s);
+  canonical_modified(env, true);  // a relabelling: the batch stays in lock step
   hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
@@ -464,6 +543,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
   a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
+  ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   if (env->pm_kernel == W2A_PM_MATRIX_I8) {
@@ -562,6 +642,8 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   a.ret_snapshot = ret_snapshot;
   a.order = env->order;
   hipStream_t s = (hipStream_t)stream;
+  ensure_canonical(env, s);
+  canonical_modified(env);
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
@@ -602,6 +684,8 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   a.ret_snapshot = ret_snapshot;
   pa.perm = env->perm; pa.tiles = env->tiles; pa.n_tiles = env->n_tiles; pa.wd = env->wd;
   hipStream_t s = (hipStream_t)stream;
+  ensure_canonical(env, s);
+  canonical_modified(env);
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
@@ -631,6 +715,7 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
   }
   a.actions = actions; a.alerts = alerts; a.attempts_over_budget = attempts_over_budget;
   a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words;
+  ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_policy_actions, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
@@ -639,8 +724,26 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
   if (!env || !view) return fail(W2A_ERR_ARG, "w2a_get_state: NULL argument");
   int64_t blocks = (env->n + 255) / 256;
+  ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->st, env->n, env->tb.Y, env->tb.n_samples, *view);
   HIP_TRY(hipGetLastError());
+  return W2A_OK;
+}
+
+int w2a_query(w2a_env *env, int what) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_query: NULL handle");
+  switch (what) {
+    case W2A_Q_LOCKSTEP_DAY: return env->uni_t;
+    case W2A_Q_PACKED_ELIGIBLE: return (env->pk_static_ok && env->budget_bound <= 65535 && env->uni_nd > 0) ? 1 : 0;
+    case W2A_Q_PACKED_CURRENT: return env->pk_valid;
+    case W2A_Q_CANONICAL_CURRENT: return env->canon_valid;
+    default: return fail(W2A_ERR_ARG, "w2a_query: unknown item");
+  }
+}
+
+int w2a_invalidate(w2a_env *env) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
+  env->pk_valid = 0; env->canon_valid = 1; env->uni_t = -1; env->perm_valid = 0; env->budget_bound = INT64_MAX;
   return W2A_OK;
 }
 

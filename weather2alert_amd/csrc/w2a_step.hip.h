@@ -20,6 +20,7 @@ struct StepArgs {
   int64_t gid0;
   ResetCfg rc;
   int32_t act_dtype;
+  int32_t uni_t, uni_nd;  // k_step64 packed variant: the day and episode length shared by every env (lock step)
   int32_t skip_finished;  // k_step64: envs whose episode is over are left untouched (reward 0, done 1, no status bit)
 };
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 // One 64-env tile of one wave, phases A..C, from the tile's already loaded state words and action.
 // REWARD_GIVEN: a.reward already holds today's reward (w2a_posterior_mean_reward ran on the same state and actions):
 // no coefficient gather and no logits here, the rest of env.py:238-262 as usual.
-template <bool WRITE_OBS, bool REWARD_GIVEN>
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED>
 __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const int lane, const int64_t wave_env0,
                                          const bool valid, const uint32_t e, const u3 h, const u3 c, const int32_t act,
                                          const int4 so) {
@@ -269,7 +269,8 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   st4_sc1(&a.reward[e], __float_as_uint(r));
   st1_sc1(&a.done[e], done ? 1u : 0u);
 #else
-  a.st.hot3[e] = h2;
+  if (PACKED) a.st.pk_hot[e] = make_uint2(pk_pack_hot(used2, streak2, hist2, done ? 1u : 0u), h2.c);
+  else a.st.hot3[e] = h2;
   if (!REWARD_GIVEN) a.reward[e] = r;
   a.done[e] = done ? 1 : 0;
 #endif
@@ -278,6 +279,19 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   }
 }
 
+// packed variant: 8 + 8 B per env, the uniform day / episode length from the kernel arguments; the canonical words are
+// rebuilt in registers so that the tile code is shared
+__device__ __forceinline__ void s64_load_packed(const StepArgs &a, uint32_t e, u3 &h, u3 &c, int32_t &act) {
+  const uint2 ph = a.st.pk_hot[e];
+  const uint2 pc = a.st.pk_c[e];
+  h.a = pack_d0((uint32_t)a.uni_t, PK_USED(ph.x), PK_STREAK(ph.x), PK_HIST(ph.x) & 1u, 0u);
+  h.b = pack_d1(PK_HIST(ph.x), (uint32_t)a.uni_nd, PK_FIN(ph.x));
+  h.c = ph.y;
+  c.a = pc.x & 0xFFFFu;
+  c.b = pc.y & 0x3FFFFFu;
+  c.c = PACK_W(pc.x >> 16, pc.y >> 22);
+  act = load_action(a, e);
+}
 __device__ __forceinline__ void s64_load_state(const StepArgs &a, uint32_t e, u3 &h, u3 &c, int32_t &act) {
 #if W2A_S64_NT_STATE & 1
   const v3u hv = __builtin_nontemporal_load(reinterpret_cast<const v3u *>(&a.st.hot3[e]));
@@ -298,7 +312,7 @@ __device__ __forceinline__ void s64_load_state(const StepArgs &a, uint32_t e, u3
 // action streams, 28 B per env) has few bytes in flight and a full memory round trip of latency; requesting the
 // NEXT tile's words before the current tile's phases run takes that hop off the wave's critical path for every
 // tile but the first (7 more VGPRs). Measured: DESIGN.md §4.
-template <bool WRITE_OBS, bool REWARD_GIVEN>
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
   const int tid = threadIdx.x;
@@ -312,7 +326,8 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
   int32_t an;
   {
     const int64_t env = wave_env0 + lane;
-    s64_load_state(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
+    if (PACKED) s64_load_packed(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
+    else s64_load_state(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
   }
   // slot -> observation column of the 4 row slots this lane owns in the row phase; requested together with the
   // state words so that its latency is not exposed in front of the gathers
@@ -329,14 +344,39 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
     const int32_t act = an;
     if (i + 1 < W2A_S64_TILES && env0 + S64_ENVS < a.n) {
       const int64_t en = env + S64_ENVS;
-      s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
+      if (PACKED) s64_load_packed(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
+      else s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
     }
-    s64_tile<WRITE_OBS, REWARD_GIVEN>(a, sw, lane, env0, valid, e, h, c, act, so);
+    s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED>(a, sw, lane, env0, valid, e, h, c, act, so);
     // the per-wave LDS record is rewritten by the next tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+}
+
+// canonical -> lock-step mirror (entering the packed form: once per episode) and back (before anything else reads the
+// canonical arrays). t / n_days / finished are uniform and come from the host's bookkeeping.
+__global__ void k_pack_state(StateArrays st, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u3 h = st.hot3[i];
+  const u3 c = st.stepc[i];
+  st.pk_hot[i] = make_uint2(pk_pack_hot(D0_USED(h.a), D0_STREAK(h.a), D1_HIST(h.b), D1_FIN(h.b)), h.c);
+  st.pk_c[i] = make_uint2((c.a & 0xFFFFu) | (W_COL(c.c) << 16), (c.b & 0x3FFFFFu) | (W_SAMPLE(c.c) << 22));
+}
+__global__ void k_unpack_state(StateArrays st, int64_t n, int32_t t, int32_t n_days) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint2 ph = st.pk_hot[i];
+  const uint32_t used = PK_USED(ph.x), hist = PK_HIST(ph.x), fin = PK_FIN(ph.x), last = hist & 1u;
+  // at_budget as the last step left it (env.py:242: decided BEFORE that day's action); False after a reset
+  const uint32_t atb = ((t > 0 || fin) && (int32_t)(used - last) == (int32_t)st.stepc[i].a) ? 1u : 0u;
+  u3 h;
+  h.a = pack_d0((uint32_t)t, used, PK_STREAK(ph.x), last, atb);
+  h.b = pack_d1(hist, (uint32_t)n_days, fin);
+  h.c = ph.y;
+  st.hot3[i] = h;
 }
 
 #endif  // W2A_STEP64_HIP_H

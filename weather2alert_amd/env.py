@@ -85,7 +85,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
                          64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
                          (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
-                         results up to the order of the fp64 additions; for A/B measurements and tests).
+                         results up to the order of the fp64 additions; for A/B measurements and tests). While the
+                         batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env
+                         state instead of the 24-B canonical words (include/w2a.h, w2a_state_bytes; identical
+                         results; ``packed_state`` says whether it is in use); "unpacked" = "auto" without it.
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -116,7 +119,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         lockstep: bool | None = None,
         faithful: bool = True,
         fixes: set | list | None = None,
-        step_kernel: Literal["auto", "classic", "wide"] = "auto",
+        step_kernel: Literal["auto", "classic", "wide", "unpacked"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         rollout_order: bool = True,
         pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "auto",
@@ -158,7 +161,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if self.fixes - allf:
             raise ValueError(f"unknown fixes {sorted(self.fixes - allf)}; choose from {sorted(allf)}")
         self.reward_path = reward_path
-        if step_kernel not in ("auto", "classic", "wide"):
+        if step_kernel not in ("auto", "classic", "wide", "unpacked"):
             raise ValueError(f"step_kernel {step_kernel!r}")
         self.step_kernel = step_kernel
         if reward_mode not in ("sampled", "posterior_mean"):
@@ -285,6 +288,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
                             (_ffi.STEP_REWARD_GIVEN if self._pm else 0) |
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_WIDE if self.step_kernel == "wide" else 0) |
+                            (_ffi.STEP_UNPACKED if self.step_kernel == "unpacked" else 0) |
                             (_ffi.STEP_AUTORESET if self._dev_auto else 0))
 
     @property
@@ -294,6 +298,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                                           self.num_envs >= _ffi.S64_MIN_ENVS)
         return "k_step64" if (wide and not self._dev_auto and not (self.fixes - {"budget"})
                               and self.step_kernel != "classic") else "k_step"
+
+    @property
+    def packed_state(self) -> bool:
+        """The library currently holds the step state in its packed lock-step form (the last step ran the packed
+        variant of the 64-envs-per-wave kernel)."""
+        return bool(self._lib.w2a_query(self._h, _ffi.Q_PACKED_CURRENT)) and not bool(
+            self._lib.w2a_query(self._h, _ffi.Q_CANONICAL_CURRENT))
 
     def _stream(self):
         if self._raw_stream is not None:
@@ -347,6 +358,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         """Everything needed to resume this batch bit-exactly: the packed per-env state (episode tuples,
         counters, returns, sticky budgets, episode numbers), the last observations and the host-side mirrors.
         (The reference env has no save/restore)"""
+        self.state()  # brings the canonical arrays up to date (the library may hold the packed lock-step form)
         return {
             "state": self._state.clone(), "obs": self._obs.clone(), "final_return": self._final_return.clone(),
             "reward": self._reward.clone(), "done": self._done.clone(),
@@ -363,6 +375,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         hdr = self._state[:256].clone()  # slot map written by w2a_create for THIS handle
         self._state.copy_(sd["state"])
         self._state[:256].copy_(hdr)
+        _ffi.check(self._lib.w2a_invalidate(self._h), "w2a_invalidate")  # the state buffer changed behind the library
         self._obs.copy_(sd["obs"])
         self._final_return.copy_(sd["final_return"])
         self._reward.copy_(sd["reward"])
@@ -811,31 +824,49 @@ class HeatAlertVecEnv(_VectorEnvBase):
     def episode_rows(out: dict) -> list[dict]:
         """One row per env in the format of the reference's FinalEvalCallback (callbacks.py:116-146) from whole-episode
         rollout outputs: year, alert_budget, sum_alerts and reward as read when env.t == n_days - 2 (:128-132), alert
-        day / streak statistics over the GRANTED alerts of the whole episode (:118-126), and the granted-alert list."""
-        act = out["alert_days"].cpu().numpy()
-        nd = out["n_days"].cpu().numpy()
-        year, bud = out["year"].cpu().numpy(), out["budget"].cpu().numpy()
-        snap = out["return_snapshot"].cpu().numpy()
+        day / streak statistics over the GRANTED alerts of the whole episode (:118-126), and the granted-alert list.
+        Every statistic is computed on the device from the day bitmaps (the same run-length formulation as
+        callback_stats, per env instead of pooled); the host only formats the rows."""
+        act = out["alert_days"]
+        n, T = act.shape
+        dev = act.device
+        nd = out["n_days"].long()
+        day = torch.arange(T, device=dev)
+        live = day[None, :] < nd[:, None]
+        a = (act & live).to(torch.int64)
+        cnt = a.sum(1)
+        # day of each granted alert as the callback sees it: env.t after the step = min(day + 1, n_days - 1)
+        t_after = torch.minimum(day[None, :] + 1, nd[:, None] - 1).double()
+        af = a.double()
+        c = cnt.clamp(min=1).double()
+        mean_t = (t_after * af).sum(1) / c
+        std_t = (((t_after - mean_t[:, None]) ** 2) * af).sum(1).div(c).sqrt()
+        # streaks of granted alerts ended by a no-alert day inside the episode: run length at the day before
+        cs = a.cumsum(1)
+        zero_c = torch.where(a == 0, cs, torch.zeros_like(cs)).cummax(1).values
+        run = (cs - zero_c)[:, :-1].double()
+        ended = ((a[:, 1:] == 0) & (a[:, :-1] == 1) & live[:, 1:]).double()
+        ns = ended.sum(1)
+        cn = ns.clamp(min=1.0)
+        mean_s = (run * ended).sum(1) / cn
+        std_s = (((run - mean_s[:, None]) ** 2) * ended).sum(1).div(cn).sqrt()
+        seen = (day[None, :] < (nd[:, None] - 2)).to(torch.int64)
+        sum_alerts = (a * seen).sum(1)
+        h = {k: v.cpu().numpy() for k, v in dict(
+            act=a.to(torch.uint8), nd=nd, year=out["year"], bud=out["budget"], snap=out["return_snapshot"], cnt=cnt,
+            mean_t=mean_t, std_t=std_t, ns=ns, mean_s=mean_s, std_s=std_s, sum_alerts=sum_alerts).items()}
         rows = []
-        for i in range(act.shape[0]):
-            a = act[i, : nd[i]].astype(np.int64)
-            when = np.minimum(np.nonzero(a)[0] + 1, nd[i] - 1)
-            streaks, cur = [], 0
-            for k in range(len(a)):
-                if a[k]:
-                    cur += 1
-                elif k > 0 and a[k - 1]:
-                    streaks.append(cur)
-                    cur = 0
-            read = nd[i] >= 3  # the callback only fills these when it sees t == n_days - 2
+        for i in range(n):
+            read = h["nd"][i] >= 3  # the callback only fills these when it sees t == n_days - 2
+            has_t, has_s = h["cnt"][i] > 0, h["ns"][i] > 0
             rows.append({
-                "year": int(year[i]) if read else 0, "alert_budget": int(bud[i]) if read else 0,
-                "sum_alerts": int(a[: nd[i] - 2].sum()) if read else 0, "reward": float(snap[i]) if read else 0,
-                "average_t_alerts": float(np.mean(when)) if len(when) else 0,
-                "stdev_t_alerts": float(np.std(when)) if len(when) else 0,
-                "average_streak": float(np.mean(streaks)) if streaks else 0,
-                "stdev_streak": float(np.std(streaks)) if streaks else 0,
-                "alerts": [int(v) for v in a] if read else []})
+                "year": int(h["year"][i]) if read else 0, "alert_budget": int(h["bud"][i]) if read else 0,
+                "sum_alerts": int(h["sum_alerts"][i]) if read else 0, "reward": float(h["snap"][i]) if read else 0,
+                "average_t_alerts": float(h["mean_t"][i]) if has_t else 0,
+                "stdev_t_alerts": float(h["std_t"][i]) if has_t else 0,
+                "average_streak": float(h["mean_s"][i]) if has_s else 0,
+                "stdev_streak": float(h["std_s"][i]) if has_s else 0,
+                "alerts": h["act"][i, : h["nd"][i]].tolist() if read else []})
         return rows
 
     @classmethod
