@@ -116,10 +116,17 @@ def main():
     logs = ["toolchain.txt", "pm_i8_variants.log", "bench.log", "pytest_gpu.log", "smoke.log", "exp_step_kernels.log", "ab_step64.log", "ab2.log", "nsweep.log",
             "bench_rollout.log", "bench_configs1.log", "bench_configs3.log", "bench_gloo2.log", "pm_trace.log",
             "pm_variants.log", "pm_tests_matrix.log", "pm_rollout.log", "mfma_overlap_probe.log"]
+    # gpurun_out/ is scratch that survives rounds: only logs written after the newest file of the other rounds'
+    # directories belong to this one
+    older = [os.path.getmtime(f) for d in glob.glob(os.path.join(ROOT, "profiles", "r*")) if os.path.abspath(d) != os.path.abspath(out)
+             for f in glob.glob(os.path.join(d, "*"))]
+    since = max(older) if older else 0.0
     for f in logs:
         src = os.path.join(GO, f)
-        if os.path.exists(src):
+        if os.path.exists(src) and os.path.getmtime(src) > since:
             shutil.copy(src, os.path.join(out, f))
+        elif os.path.exists(src):
+            print(f"{f}: older than the previous round's evidence, not copied")
 
 
 if __name__ == "__main__":

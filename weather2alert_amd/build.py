@@ -34,17 +34,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > m for d in deps)
 
 
-STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_kernels.hip")
+STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_step_dispatch.hip.h")
 
 
 def source_sha(files: tuple = STEP_SOURCES) -> str:
-    """sha256 over the sources the step kernels are built from and the ABI header (file names + contents):
-    identifies the build a step-kernel profile was collected on, independently of commits that do not touch them."""
+    """sha256 over the sources the step kernels and their dispatch are built from (file names + contents): identifies
+    the build a step-kernel profile was collected on, independently of commits that do not touch them."""
     import hashlib
 
     h = hashlib.sha256()
     csrc = os.path.dirname(SRC)
-    for path in [os.path.join(csrc, f) for f in sorted(files)] + [os.path.join(INC, "w2a.h")]:
+    for path in [os.path.join(csrc, f) for f in sorted(files)]:
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]

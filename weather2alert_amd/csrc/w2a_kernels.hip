@@ -303,89 +303,7 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
   return W2A_OK;
 }
 
-int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, float *reward, uint8_t *done,
-             float *last_return, int flags, void *stream) {
-  if (!env || !actions || !reward || !done) return fail(W2A_ERR_ARG, "w2a_step: NULL argument");
-  if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_step: bad action_dtype");
-  const bool no_obs = (flags & W2A_STEP_NO_OBS) != 0;
-  const bool autoreset = (flags & W2A_STEP_AUTORESET) != 0;
-  const bool given = (flags & W2A_STEP_REWARD_GIVEN) != 0;
-  if (given && (autoreset || env->tb.fixes || (flags & W2A_STEP_CLASSIC)))
-    return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is served by the 64-envs-per-wave kernel only (no in-kernel "
-                             "autoreset, no corrected-semantics flags)");
-  if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
-  if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
-  if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
-  if (autoreset) env->perm_valid = 0;  // envs that finish draw new coefficient columns inside the kernel
-  StepArgs a;
-  memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
-  a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
-  a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
-  a.skip_finished = (flags & W2A_STEP_SKIP_FINISHED) ? 1 : 0;
-  if (a.skip_finished && !given)
-    return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_SKIP_FINISHED goes with W2A_STEP_REWARD_GIVEN (policy loops)");
-  dim3 grid(grid_for(env->n)), block(BLOCK);
-  hipStream_t s = (hipStream_t)stream;
-#if W2A_F64_SIGMOID
-  if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
-#else
-  // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
-  // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
-  const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
-  // the day every env is on after this call, if the batch is (still) known to be in lock step: a plain step moves all
-  // of them to the next day; the terminal step, an in-kernel autoreset or unknown state ends the knowledge
-  const int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
-  if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
-    // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
-    // multiple of 8 workgroups
-    const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
-    const int64_t tiles = (env->n + per_wg - 1) / per_wg;
-    dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
-    // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
-    const bool packed = !given && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
-                        env->budget_bound <= 65535;
-    if (packed) {
-      if (!env->pk_valid) {  // entering the packed form (once per episode): the canonical arrays are current
-        hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);
-        env->pk_valid = 1;
-      }
-      a.uni_t = env->uni_t; a.uni_nd = env->uni_nd;
-      if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
-      else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
-      HIP_TRY(hipGetLastError());
-      env->canon_valid = 0;
-      env->pk_t = uni_next >= 0 ? uni_next : env->uni_t;  // the terminal step leaves t where it is (env.py:256-259)
-      env->uni_t = uni_next;
-      return W2A_OK;
-    }
-    ensure_canonical(env, s);
-    canonical_modified(env, true);
-    env->uni_t = uni_next;
-    if (given) {
-      if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
-      else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
-    } else {
-      if (no_obs) hipLaunchKernelGGL((k_step64<false, false>), grid64, block, 0, s, a);
-      else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return W2A_OK;
-  }
-#endif
-  ensure_canonical(env, s);
-  canonical_modified(env, true);
-  env->uni_t = uni_next;
-#define W2A_LAUNCH(AR, OB) \
-  do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, true>), grid, block, 0, s, a); \
-       else hipLaunchKernelGGL((k_step<AR, OB, false>), grid, block, 0, s, a); } while (0)
-  if (autoreset) { if (no_obs) W2A_LAUNCH(true, false); else W2A_LAUNCH(true, true); }
-  else { if (no_obs) W2A_LAUNCH(false, false); else W2A_LAUNCH(false, true); }
-#undef W2A_LAUNCH
-  HIP_TRY(hipGetLastError());
-  return W2A_OK;
-}
-
+#include "w2a_step_dispatch.hip.h"
 
 static size_t cub_sort_bytes(int64_t n) {
   size_t b = 0;
