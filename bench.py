@@ -455,6 +455,18 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
         ea.reset(seed=args.seed)
         res["auto_choice"] = ea.pm_kernel_choice
         res["auto_timing_us"] = ea.pm_kernel_timing_us
+        # the evaluation sweep of the legacy eval mode: a whole 153-day episode per launch with this reward
+        rpol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
+        ea.rollout(rpol)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            ea.rollout(rpol)
+        torch.cuda.synchronize()
+        dt_r = (time.perf_counter() - t0) / 2
+        res["rollout"] = {"kernel": ea.pm_kernel_choice, "ms_per_episode": dt_r * 1e3, "value": n * ct.T / dt_r,
+                          "unit": "env-steps/s", "note": "rollout(): threshold policy, one launch per 153-day episode "
+                          "(k_pm_rollout_i8 / k_pm_rollout), grouping by column included"}
         ea.close()
         best = min(res["kernels"], key=lambda k: res["kernels"][k]["us_per_step"])
         res.update(us_per_step=res["kernels"][best]["us_per_step"], value=res["kernels"][best]["value"], fastest=best,

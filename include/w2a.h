@@ -268,9 +268,11 @@ size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows);
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* w2a_rollout with the posterior-mean reward (w2a_posterior_mean_reward's value every day), whole episode in one launch:
- * same arguments and outputs as w2a_rollout; needs w2a_group_by_column after the last reset. Returns 1 (nothing done)
- * when the one-launch kernel does not apply -- more posterior draws than one LDS staging pass holds, coefficients on
- * slots 28/30/31 -- and the caller runs the per-day sequence w2a_policy_actions, w2a_posterior_mean_reward, w2a_step. */
+ * same arguments and outputs as w2a_rollout; needs w2a_group_by_column after the last reset. Built on the kernel selected
+ * by w2a_set_posterior_kernel: W2A_PM_MATRIX_I8 (k_pm_rollout_i8) or W2A_PM_VECTOR (k_pm_rollout). Returns 1 (nothing
+ * done) when no one-launch kernel applies -- more posterior draws than one LDS staging pass holds (112), the vector form
+ * with coefficients on slots 28/30/31, W2A_PM_MATRIX_F64 -- and the caller runs the per-day sequence w2a_policy_actions,
+ * w2a_posterior_mean_reward, w2a_step. */
 int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *ret_out,
                                int32_t *alerts_out, int32_t *attempts_over_budget, uint32_t *alert_mask,
                                uint32_t *attempt_mask, int32_t mask_words, float *last_return, float *ret_snapshot,

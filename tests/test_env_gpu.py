@@ -1190,12 +1190,16 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_ke
     env.close()
 
 
-@pytest.mark.parametrize("one_launch", [True, False])
-def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_launch):
+@pytest.mark.parametrize("one_launch,pm_kernel,budget", [(True, "vector", 120), (False, "vector", 120),
+                                                         (True, "matrix_i8", 28), (True, "matrix_i8", 120)])
+def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_launch, pm_kernel, budget):
     """k_pm_rollout's effectiveness loop beyond what the small case reaches: 3 coefficient columns x ~500 envs (full
     512-row tiles and partial ones), 100 posterior draws (close to the 112 one staging pass holds), an always-alert
     policy with a large budget, i.e. far more than 64 open-gate alerts per tile and day (several row groups, R = 4,
-    s_ax / s_part reuse). One launch and the per-day sequence against the oracle's policy loop on the all-draws reward."""
+    s_ax / s_part reuse). One launch and the per-day sequence against the oracle's policy loop on the all-draws reward.
+    The int8 one-launch kernel (k_pm_rollout_i8) on the same workload: with budget 28 the run-time slots stay inside the
+    fixed-point range (matrix-core path, several effectiveness row tiles per workgroup), with budget 120 the streak
+    range pushes the columns outside it and every tile runs the kernel's exact fp64 path."""
     from weather2alert_amd import HeatAlertVecEnv
 
     sd = synth.make_synth("linear", n_fips=3, years=[2006, 2007], n_samples=100, seed=41)
@@ -1203,9 +1207,9 @@ def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years, reward_mode="posterior_mean")
     n = 1500 + 11
     env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean",
-                          pm_kernel="vector")
+                          pm_kernel=pm_kernel)
     env.pm_rollout_kernel = one_launch
-    env.reset(seed=8, options={"budget": 120})
+    env.reset(seed=8, options={"budget": budget})
     _oracle_for_env(env, V)
     pol = dict(kind="always")
     days = 24
@@ -1220,8 +1224,9 @@ def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_
     env.close()
 
 
-@pytest.mark.parametrize("one_launch", [True, False])
-def test_posterior_mean_rollout_after_a_masked_reset(dev, one_launch):
+@pytest.mark.parametrize("one_launch,pm_kernel", [(True, "vector"), (False, "vector"), (True, "matrix_i8"),
+                                                  (False, "matrix_i8")])
+def test_posterior_mean_rollout_after_a_masked_reset(dev, one_launch, pm_kernel):
     """reward_mode='posterior_mean' with autoreset='disabled' after a masked reset: the batch has left lock step (half
     the envs are on day 30, half on day 0). rollout() must serve every env on its own day and episode length -- envs
     that finish early take no further part: no second terminal step, no reward added to a finished return."""
@@ -1232,7 +1237,7 @@ def test_posterior_mean_rollout_after_a_masked_reset(dev, one_launch):
     rd = O.RefData.from_synth(sd)
     n, gid0 = 600, 50
     env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", reward_mode="posterior_mean", env_gid0=gid0,
-                          pm_kernel="vector")
+                          pm_kernel=pm_kernel)
     env.pm_rollout_kernel = one_launch
     env.reset(seed=3, options={"budget": 6})
     rng = np.random.default_rng(1)

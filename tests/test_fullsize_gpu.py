@@ -277,8 +277,9 @@ def test_full_size_posterior_mean_step_vs_oracle(dev, pm_kernel):
         V.reward_mode = "sampled"
 
 
-def test_full_size_posterior_mean_rollout_vs_oracle(dev):
-    """rollout() through k_pm_rollout (one launch per episode) at 1 048 576 envs, S = 746, 100 draws, augmented:
+@pytest.mark.parametrize("pm_kernel", ["vector", "matrix_i8"])
+def test_full_size_posterior_mean_rollout_vs_oracle(dev, pm_kernel):
+    """rollout() through k_pm_rollout / k_pm_rollout_i8 (one launch per episode) at 1 048 576 envs, S = 746, 100 draws, augmented:
     whole episode against the oracle's policy loop on the all-draws reward for ~1 024 sampled envs; the per-day
     sequence on the matrix kernel agrees with it on every env for the first days."""
     from weather2alert_amd import HeatAlertVecEnv
@@ -288,7 +289,7 @@ def test_full_size_posterior_mean_rollout_vs_oracle(dev):
     try:
         n, gid0 = 1 << 20, 777
         env = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=True, autoreset="disabled",
-                              reward_mode="posterior_mean", pm_kernel="vector", env_gid0=gid0)
+                              reward_mode="posterior_mean", pm_kernel=pm_kernel, env_gid0=gid0)
         env.reset(seed=23)
         idx = _sample(n, 1024)
         it = torch.as_tensor(idx, device=dev)

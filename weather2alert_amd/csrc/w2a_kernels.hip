@@ -42,6 +42,7 @@
 #include "w2a_posterior_i8.hip.h"
 #include "w2a_reset.hip.h"
 #include "w2a_rollout.hip.h"
+#include "w2a_rollout_i8.hip.h"
 #include "w2a_sort.hip.h"
 
 // ----------------------------------------------------------------------------------------
@@ -583,9 +584,12 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   if (!env->perm_valid)
     return fail(W2A_ERR_STATE, "w2a_rollout_posterior_mean: call w2a_group_by_column after every reset");
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: not available with corrected-semantics flags");
-  // not applicable (more draws than one staging pass holds, coefficients on slots 28/30/31, or the matrix kernel was
-  // selected: the one-launch kernel is built on the vector form): the caller runs the per-day calls
-  if (env->tb.n_samples > W2A_PMV_NPAD || env->w_tail_used || env->pm_kernel != W2A_PM_VECTOR) return 1;
+  // not applicable (more draws than one staging pass holds; vector form: coefficients on slots 28/30/31; the fp64 matrix
+  // kernel has no one-launch form): the caller runs the per-day calls
+  const bool i8 = env->pm_kernel == W2A_PM_MATRIX_I8;
+  if (env->pm_kernel == W2A_PM_MATRIX_F64 || (i8 && env->tb.n_samples > PI8_NPAD) ||
+      (!i8 && (env->tb.n_samples > W2A_PMV_NPAD || env->w_tail_used)))
+    return 1;
   PmRolloutArgs pa;
   memset(&pa, 0, sizeof(pa));
   RolloutArgs &a = pa.r;
@@ -606,6 +610,15 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   canonical_modified(env);
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
+  if (i8) {
+    PmI8RolloutArgs ia;
+    ia.r = a; ia.perm = env->perm; ia.tiles = env->tiles_i8; ia.n_tiles = env->n_tiles_i8; ia.wq = env->wq;
+    ia.wscale = env->wscale; ia.colflag = env->colflag; ia.xs = env->xs;
+    const unsigned grid8 = (unsigned)((max_tiles_i8(env->n, env->tb.S) + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_pm_rollout_i8, dim3(grid8), dim3(PI8_THREADS), 0, s, ia);
+    HIP_TRY(hipGetLastError());
+    return W2A_OK;
+  }
   const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
   launch_pm_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, grid, s, pa);
   HIP_TRY(hipGetLastError());

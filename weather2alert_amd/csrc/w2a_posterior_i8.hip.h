@@ -159,6 +159,140 @@ __device__ __forceinline__ float pi8_add_dpp(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// ---- pieces shared by k_posterior_mean_i8 (one day per launch) and k_pm_rollout_i8 (a whole episode per launch) ------
+// a row's 32 floats -> fixed-point digits -> its 128 B of the X image (4 planes x 32 slots; 8 x 16-B stores, consecutive
+// rows sit 4 banks apart)
+__device__ __forceinline__ void pi8_store_row(const float4 (&xf)[ROWF / 4], const float *xs, uint32_t *row) {
+  uint32_t pl[4][ROWF / 4];
+#pragma unroll
+  for (int g = 0; g < ROWF / 4; ++g) {
+    uint32_t d[4], o[4];
+    d[0] = pi8_digits((int32_t)(xf[g].x * xs[4 * g]));      // truncating convert: |x| < 2^ex_k by construction
+    d[1] = pi8_digits((int32_t)(xf[g].y * xs[4 * g + 1]));
+    d[2] = pi8_digits((int32_t)(xf[g].z * xs[4 * g + 2]));
+    d[3] = pi8_digits((int32_t)(xf[g].w * xs[4 * g + 3]));
+    pi8_planes(d, o);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) pl[p][g] = o[p];
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(row);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    dst[2 * p] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    dst[2 * p + 1] = make_uint4(pl[p][4], pl[p][5], pl[p][6], pl[p][7]);
+  }
+}
+// the wave's A fragments: row tiles wave, wave + 4, ...; lane (c16, q) holds 16 slots of one plane of row c16
+__device__ __forceinline__ void pi8_load_a(const uint32_t (*sX)[PI8_XSTRIDE], int wave, int lane, pi8_v4i *P, pi8_v4i *Q) {
+  const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
+    const uint32_t *r = sX[(wave + i * PI8_WAVES) * 16 + c16];
+    P[i] = *reinterpret_cast<const pi8_v4i *>(r + 4 * q);        // (X0 | X1): 16 slots of one plane per lane group
+    Q[i] = *reinterpret_cast<const pi8_v4i *>(r + 16 + 4 * q);   // (X2 | X3)
+  }
+}
+// all column tiles of the staged draws for the wave's row tiles: rs[i][j] += sum over this lane's draw columns of
+// sigmoid(zb) [* (1 - sigmoid(ze) * ga)] for accumulator row 4 q + j of row tile wave + 4 i
+__device__ __forceinline__ void pi8_accumulate(const uint32_t (*sW)[PI8_WSTRIDE], const float *sScale, const float *sGa,
+                                               const pi8_v4i *P, const pi8_v4i *Q, float (*rs)[4], int ntiles, int draws,
+                                               int rows, int eff_tiles, int wave, int lane) {
+  const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll 1
+  for (int nt = 0; nt < ntiles; ++nt) {
+    const int dcol = nt * 16 + c16;        // this lane's draw (accumulator column)
+    const int drow = dcol * 2;             // its scale entries: drow + head
+    const float dvalid = dcol < draws ? 1.0f : 0.0f;  // draws past the end (zero digits -> sigmoid 0.5) count 0
+    // B_m = (W_m | W_{m-1}): lane groups 0,1 read plane m, groups 2,3 plane m-1 (zero for m = 0)
+    auto load_b = [&](int head, pi8_v4i *B) {
+      const uint32_t *w = &sW[dcol][head * ROWF];
+      const int half = 4 * (q & 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int plane = q < 2 ? m : m - 1;
+        const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(w + 8 * max(plane, 0) + half);
+        B[m] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
+      }
+    };
+    // (packed f32 forms of this epilogue -- v_pk_mul / v_pk_fma / v_pk_add on register pairs -- measured 4 % slower)
+    auto logits = [&](const pi8_v4i &Pm, const pi8_v4i &Qm, const pi8_v4i *B, float sc, float *z) {
+      const pi8_v4i zero = {0, 0, 0, 0};
+      pi8_v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[0], zero, 0, 0, 0);
+      pi8_v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[1], zero, 0, 0, 0);
+      pi8_v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[2], zero, 0, 0, 0);
+      pi8_v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[3], zero, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[0], a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[1], a3, 0, 0, 0);
+      const float sc16 = sc * 1.52587890625e-05f;  // 2^-16
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = (float)(a0[j] * 256 + a1[j]);
+        const float v = (float)(a2[j] * 256 + a3[j]);
+        z[j] = fmaf(v, sc16, u * sc);  // = -log2(e) * logit
+      }
+    };
+    pi8_v4i B0[4], B1[4];
+    load_b(0, B0);
+    const float sc0 = sScale[drow];
+#pragma unroll
+    for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
+      const int mt = wave + i * PI8_WAVES;
+      if (mt * 16 >= rows) continue;  // wave-uniform: no row of the tile in this row tile
+      float zb[4], t[4];
+      logits(P[i], Q[i], B0, sc0, zb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zb[j]));
+      if (mt < eff_tiles) {  // wave-uniform: rows with an open gate AND an alert today sit in the first row tiles
+        load_b(1, B1);
+        float ze[4];
+        logits(P[i], Q[i], B1, sScale[drow + 1], ze);
+        const float4 ga4 = *reinterpret_cast<const float4 *>(&sGa[mt * 16 + 4 * q]);  // accumulator row = 4 q + j
+        const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= 1.0f - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ze[j])) * ga[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rs[i][j] = fmaf(t[j], dvalid, rs[i][j]);
+    }
+  }
+}
+// sum over the 16 lanes (draw columns) of each lane group, one value per row of the image -> sSum
+__device__ __forceinline__ void pi8_reduce(const float (*rs)[4], float *sSum, int wave, int lane) {
+  const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = rs[i][j];
+      v = pi8_add_dpp<0xB1>(v);   // lane ^ 1
+      v = pi8_add_dpp<0x4E>(v);   // lane ^ 2
+      v = pi8_add_dpp<0x141>(v);  // row_half_mirror
+      v = pi8_add_dpp<0x140>(v);  // row_mirror
+      if (c16 == 0) sSum[(wave + i * PI8_WAVES) * 16 + 4 * q + j] = v;
+    }
+  }
+}
+// exact fp64 reward sum of one row for a column outside the fixed-point range (uniform addresses into W)
+__device__ __forceinline__ double pi8_exact_row(const float4 (&xf)[ROWF / 4], const float4 *W, uint32_t col, int n_samples,
+                                                uint32_t ga) {
+  const float *xr = reinterpret_cast<const float *>(xf);
+  double sum = 0.0;
+  for (int s = 0; s < n_samples; ++s) {
+    const float *wr = reinterpret_cast<const float *>(W) + ((size_t)col * n_samples + s) * (2 * ROWF);
+    double zb = 0.0, ze = 0.0;
+#pragma unroll
+    for (int k = 0; k < ROWF; ++k) zb = fma((double)xr[k], (double)wr[k], zb);
+    float t = sigmoid_f32((float)zb);
+    if (ga) {
+#pragma unroll
+      for (int k = 0; k < ROWF; ++k) ze = fma((double)xr[k], (double)wr[ROWF + k], ze);
+      t *= 1.0f - sigmoid_f32((float)ze);
+    }
+    sum += (double)t;
+  }
+  return sum;
+}
+
 #ifndef W2A_PI8_MIN_WAVES
 #define W2A_PI8_MIN_WAVES 4  // waves/SIMD the kernel is compiled for: 4 workgroups of 40 KB LDS per CU, <= 128 VGPRs
 #endif
@@ -217,24 +351,8 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
   const uint32_t ga = (tid < rows) ? (rec.y >> 15) & 1u : 0u;
   if (a.colflag[col]) {
     // ---- exact path for a column outside the fixed-point range: fp64 dot products straight from W (uniform addresses)
-    if (tid < rows) {
-      const float *xr = reinterpret_cast<const float *>(xf);
-      double sum = 0.0;
-      for (int s = 0; s < n_samples; ++s) {
-        const float *wr = reinterpret_cast<const float *>(a.p.tb.W) + ((size_t)col * n_samples + s) * (2 * ROWF);
-        double zb = 0.0, ze = 0.0;
-#pragma unroll
-        for (int k = 0; k < ROWF; ++k) zb = fma((double)xr[k], (double)wr[k], zb);
-        float t = sigmoid_f32((float)zb);
-        if (ga) {
-#pragma unroll
-          for (int k = 0; k < ROWF; ++k) ze = fma((double)xr[k], (double)wr[ROWF + k], ze);
-          t *= 1.0f - sigmoid_f32((float)ze);
-        }
-        sum += (double)t;
-      }
-      a.p.reward[rec.w] = (float)(-(1000.0 / 152.0) * sum / (double)n_samples);
-    }
+    if (tid < rows)
+      a.p.reward[rec.w] = (float)(-(1000.0 / 152.0) * pi8_exact_row(xf, a.p.tb.W, col, n_samples, ga) / (double)n_samples);
     return;
   }
   // ---- rows with gate * actual = 1 first (stable partition inside the workgroup)
@@ -252,40 +370,14 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
   sEnv[pos] = rec.w;
   sGa[pos] = (float)ga;
   // ---- fixed-point digits of the row -> LDS image
-  {
-    const float *xs = a.xs;
-    uint32_t pl[4][ROWF / 4];
-#pragma unroll
-    for (int g = 0; g < ROWF / 4; ++g) {
-      uint32_t d[4], o[4];
-      d[0] = pi8_digits((int32_t)(xf[g].x * xs[4 * g]));      // truncating convert: |x| < 2^ex_k by construction
-      d[1] = pi8_digits((int32_t)(xf[g].y * xs[4 * g + 1]));
-      d[2] = pi8_digits((int32_t)(xf[g].z * xs[4 * g + 2]));
-      d[3] = pi8_digits((int32_t)(xf[g].w * xs[4 * g + 3]));
-      pi8_planes(d, o);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) pl[p][g] = o[p];
-    }
-    uint4 *dst = reinterpret_cast<uint4 *>(sX[pos]);  // 8 x 16-B stores; consecutive rows sit 4 banks apart
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      dst[2 * p] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
-      dst[2 * p + 1] = make_uint4(pl[p][4], pl[p][5], pl[p][6], pl[p][7]);
-    }
-  }
-  const int q = lane >> 4, c16 = lane & 15;
+  pi8_store_row(xf, a.xs, sX[pos]);
   const int eff_tiles = (int)((n_eff + 15u) >> 4);
   float rs[PI8_MT_PER_WAVE][4];  // per lane: sums over its draw columns of the 4 accumulator rows
 #pragma unroll
   for (int i = 0; i < PI8_MT_PER_WAVE; ++i) rs[i][0] = rs[i][1] = rs[i][2] = rs[i][3] = 0.0f;
   pi8_v4i P[PI8_MT_PER_WAVE], Q[PI8_MT_PER_WAVE];
   __syncthreads();  // the X image is complete
-#pragma unroll
-  for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
-    const uint32_t *row = sX[(wave + i * PI8_WAVES) * 16 + c16];
-    P[i] = *reinterpret_cast<const pi8_v4i *>(row + 4 * q);        // (X0 | X1): 16 slots of one plane per lane group
-    Q[i] = *reinterpret_cast<const pi8_v4i *>(row + 16 + 4 * q);   // (X2 | X3)
-  }
+  pi8_load_a(sX, wave, lane, P, Q);
   for (int n0 = 0; n0 < n_samples; n0 += PI8_NPAD) {
     const int draws = min(PI8_NPAD, n_samples - n0);
     const int ntiles = (draws + 15) >> 4;
@@ -298,77 +390,9 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
     }
     if (tid < PI8_NPAD * 2) sScale[tid] = screg;
     __syncthreads();
-#pragma unroll 1
-    for (int nt = 0; nt < ntiles; ++nt) {
-      const int dcol = nt * 16 + c16;        // this lane's draw (accumulator column)
-      const int drow = dcol * 2;             // its scale entries: drow + head
-      const float dvalid = nt * 16 + c16 < draws ? 1.0f : 0.0f;  // draws past the end (zero digits -> sigmoid 0.5) count 0
-      // B_m = (W_m | W_{m-1}): lane groups 0,1 read plane m, groups 2,3 plane m-1 (zero for m = 0)
-      auto load_b = [&](int head, pi8_v4i *B) {
-        const uint32_t *w = &sW[dcol][head * ROWF];
-        const int half = 4 * (q & 1);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int plane = q < 2 ? m : m - 1;
-          const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(w + 8 * max(plane, 0) + half);
-          B[m] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
-        }
-      };
-      // (packed f32 forms of this epilogue -- v_pk_mul / v_pk_fma / v_pk_add on register pairs -- measured 4 % slower)
-      auto logits = [&](const pi8_v4i &Pm, const pi8_v4i &Qm, const pi8_v4i *B, float sc, float *z) {
-        const pi8_v4i zero = {0, 0, 0, 0};
-        pi8_v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[0], zero, 0, 0, 0);
-        pi8_v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[1], zero, 0, 0, 0);
-        pi8_v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[2], zero, 0, 0, 0);
-        pi8_v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[3], zero, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[0], a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[1], a3, 0, 0, 0);
-        const float sc16 = sc * 1.52587890625e-05f;  // 2^-16
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float u = (float)(a0[j] * 256 + a1[j]);
-          const float v = (float)(a2[j] * 256 + a3[j]);
-          z[j] = fmaf(v, sc16, u * sc);  // = -log2(e) * logit
-        }
-      };
-      pi8_v4i B0[4], B1[4];
-      load_b(0, B0);
-      const float sc0 = sScale[drow];
-#pragma unroll
-      for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
-        const int mt = wave + i * PI8_WAVES;
-        if (mt * 16 >= rows) continue;  // wave-uniform: no row of the tile in this row tile
-        float zb[4], t[4];
-        logits(P[i], Q[i], B0, sc0, zb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zb[j]));
-        if (mt < eff_tiles) {  // wave-uniform: rows with an open gate AND an alert today sit in the first row tiles
-          load_b(1, B1);
-          float ze[4];
-          logits(P[i], Q[i], B1, sScale[drow + 1], ze);
-          const float4 ga4 = *reinterpret_cast<const float4 *>(&sGa[mt * 16 + 4 * q]);  // accumulator row = 4 q + j
-          const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] *= 1.0f - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ze[j])) * ga[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rs[i][j] = fmaf(t[j], dvalid, rs[i][j]);
-      }
-    }
+    pi8_accumulate(sW, sScale, sGa, P, Q, rs, ntiles, draws, rows, eff_tiles, wave, lane);
   }
-  // ---- sum over the 16 lanes (draw columns) of each lane group, one value per row
-#pragma unroll
-  for (int i = 0; i < PI8_MT_PER_WAVE; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = rs[i][j];
-      v = pi8_add_dpp<0xB1>(v);   // lane ^ 1
-      v = pi8_add_dpp<0x4E>(v);   // lane ^ 2
-      v = pi8_add_dpp<0x141>(v);  // row_half_mirror
-      v = pi8_add_dpp<0x140>(v);  // row_mirror
-      if (c16 == 0) sSum[(wave + i * PI8_WAVES) * 16 + 4 * q + j] = v;
-    }
-  }
+  pi8_reduce(rs, sSum, wave, lane);
   __syncthreads();
   if (tid < rows) a.p.reward[sEnv[tid]] = -(1000.0f / 152.0f) * sSum[tid] / (float)n_samples;
 }
