@@ -587,9 +587,24 @@ def main():
         # steps (RCCL runs it on the process group's stream); it is waited for before the next one and at the end
         gather.gather(env._final_return, async_op=world > 1)
 
+    seg_events = []  # (start, end) HIP events around the step launches of each episode inside the timed region
+    seg_on = False
+    packed_seen = []
+
     def one_step():
         nonlocal stepno
+        phase = stepno % T
+        if seg_on and env._host_auto and phase == 0:  # first day of an episode: nothing but step kernels until day T-2
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            seg_events.append([ev, None])
         env.step(pool[stepno & 15])
+        if seg_on and phase == 1:
+            packed_seen.append(env.packed_state)  # host-side bookkeeping only: no device work, no sync
+        if seg_on and env._host_auto and phase == T - 2 and seg_events and seg_events[-1][1] is None:
+            ev = torch.cuda.Event(enable_timing=True)  # after day T-2: the terminal step's call also launches the reset
+            ev.record()
+            seg_events[-1][1] = ev
         stepno += 1
         if stepno % T == 0:  # lock step: every env just finished an episode
             gather_returns()
@@ -627,8 +642,10 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     if graph is None:
+        seg_on = True
         for _ in range(args.steps):
             one_step()
+        seg_on = False
     else:
         for _ in range(args.steps // args.graph):
             graph.replay()
@@ -650,14 +667,23 @@ def main():
     # step-kernel launch time, live: HIP events on the launch stream around back-to-back launches inside one
     # episode (no reset kernel, no collective in between); rocprofv3 --kernel-trace of this command must agree
     kernel_us = None
-    if graph is None:
+    kernel_timing = None
+    segs = [(a, b) for a, b in seg_events if b is not None]
+    if segs:
+        # the step launches of the TIMED REGION itself: per episode the T-1 back-to-back launches from its first day to
+        # the day before the terminal one (whose call also launches the reset kernel)
+        kernel_us = sum(a.elapsed_time(b) for a, b in segs) * 1e3 / (len(segs) * (T - 1))
+        kernel_timing = (f"HIP events on the launch stream around the {T - 1} back-to-back step launches of each of the "
+                         f"{len(segs)} whole episodes inside the timed region (reset kernels and collectives excluded)")
+    elif graph is None:
         k_steps = min(T - 2, 140)
         if env._host_auto and T - env._steps_in_episode <= k_steps:
             for _ in range(T - env._steps_in_episode):
                 env.step(pool[0])  # finish this episode: the measurement must not contain a reset kernel
         kms, _ = timed_steps(env, pool, k_steps, torch)
         kernel_us = kms * 1e3 / k_steps
-    packed = env.packed_state  # the form the step kernel streamed in the measured launches
+    # the form of the per-env state the step kernel streamed in the measured launches
+    packed = all(packed_seen) if (segs and packed_seen) else env.packed_state
 
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
@@ -733,8 +759,8 @@ def main():
                                              "note": "SURVEY 8d charges a 100-B feature row and two 112-B coefficient "
                                                      "rows per env-step to HBM; they are cache-resident, so this "
                                                      "figure is not an HBM rate and may exceed the peak"},
-                         "timing": "HIP events on the launch stream around back-to-back step launches inside one "
-                                   "episode / launches"},
+                         "timing": kernel_timing or "HIP events on the launch stream around back-to-back step launches "
+                                                     "inside one episode, right after the timed region / launches"},
             "kernel_env_steps_per_sec_per_gpu": n / per_launch_s,
             "rccl_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "collective_ms": collective_ms,

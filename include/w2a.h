@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 11
+#define W2A_ABI_VERSION 12
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -130,7 +130,9 @@ const char *w2a_last_error(void);
  * env in and 8 B out instead of 12 + 12 and 12 (needs T <= 255, S < 65536, n_samples <= 1024, S_w * Y < 2^22 and
  * budgets <= 65535; anything else uses the canonical arrays). The library converts between the two forms by itself
  * whenever an entry point needs the other one; a caller that rewrites the state buffer behind the library's back
- * (checkpoint restore) must call w2a_invalidate. */
+ * (checkpoint restore) must call w2a_invalidate. Stream capture: a w2a_step recorded into a hipGraph always uses the
+ * canonical form (the packed kernel takes the day as an argument, which a replay would not advance), and the handle
+ * keeps to it from then on. */
 size_t w2a_state_bytes(int64_t num_envs);
 
 /* Replaces HeatAlertEnv.__init__ (env.py:20-105) for `num_envs` envs whose global ids are
@@ -299,6 +301,11 @@ int w2a_query(w2a_env *env, int what);
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived
  * form (lock-step mirror, column grouping, what is known about days and budgets). */
 int w2a_invalidate(w2a_env *env);
+/* The library tracks an upper bound of every env's budget from the reset arguments (the packed lock-step form holds
+ * budgets in 16 bits). Budgets handed over in DEVICE memory (w2a_reset with a budget array, a restored checkpoint) are
+ * unknown to it and switch the packed form off; a caller that knows their maximum says so here (bound < 0: unknown
+ * again). The bound never drops below what earlier resets may have left behind as sticky budgets. */
+int w2a_set_budget_bound(w2a_env *env, int64_t bound);
 
 /* Synchronise `stream`, read and clear the device status word (host int out). */
 int w2a_read_status(w2a_env *env, int32_t *status_out, void *stream);

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 11
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 12
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)

@@ -1026,6 +1026,43 @@ def test_step_is_hipgraph_capturable(dev):
     assert (eager.state()["episode_no"] == 1).all() and torch.equal(eager.state()["t"], cap.state()["t"])
     eager.close()
     cap.close()
+    # A lock-step batch large enough for the 64-envs-per-wave kernel: eagerly it streams the packed state with the day
+    # as a kernel ARGUMENT -- which a graph replay would not advance. A captured w2a_step therefore runs the canonical
+    # kernel, and the handle keeps to the canonical form afterwards; results equal the eager (packed) env bit for bit.
+    from weather2alert_amd import _ffi
+
+    n2, G2 = 131072 + 5, 6
+    acts2 = [(torch.rand(n2, generator=g) < 0.25).to(torch.int32).to(dev) for _ in range(G2)]
+    eager = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
+    cap = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
+    eager.reset(seed=8)
+    cap.reset(seed=8)
+    eager.step(acts2[0])
+    cap.step(acts2[0])
+    assert eager.packed_state and cap.packed_state
+    cap.state()  # brings the canonical form up to date: a capture must not start on the packed form
+    graph2 = torch.cuda.CUDAGraph()
+    ck = cap.state_dict()
+    with torch.cuda.graph(graph2):
+        for a in acts2:
+            cap.step(a)
+    cap.load_state_dict(ck)
+    assert not cap.packed_state and cap._lib.w2a_query(cap._h, _ffi.Q_LOCKSTEP_DAY) == -1
+    for rep in range(3):
+        graph2.replay()
+        for a in acts2:
+            o, r, d, _, _ = eager.step(a)
+        torch.cuda.synchronize()
+        assert eager.packed_state
+        assert torch.equal(cap._obs, o) and torch.equal(cap._reward, r) and torch.equal(cap._done_bool, d)
+    se, sc = eager.state(), cap.state()
+    for k in se:
+        assert torch.equal(se[k], sc[k]), k
+    cap.reset(seed=9)  # even after a full reset a captured handle stays on the canonical form
+    cap.step(acts2[0])
+    assert not cap.packed_state
+    eager.close()
+    cap.close()
 
 
 def test_other_schema_parity(dev):

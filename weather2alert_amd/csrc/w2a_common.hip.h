@@ -188,6 +188,9 @@ struct w2a_env {
   int pk_valid, canon_valid, pk_static_ok;
   int32_t uni_t, uni_nd, pk_t, b0_max;
   int64_t budget_bound;  // no env's budget exceeds this (INT64_MAX: unknown)
+  int64_t budget_bound_known;  // its last known value (w2a_set_budget_bound restores knowledge after a reset with
+                               // caller-chosen budgets in device memory)
+  int graph_captured;    // a w2a_step of this handle was recorded into a hipGraph: canonical form only from then on
   int pm_kernel;         // W2A_PM_* : which posterior-mean reward kernel w2a_posterior_mean_reward launches
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };

@@ -127,6 +127,7 @@ static void canonical_modified(w2a_env *env, bool keeps_lockstep = false) {
   if (!keeps_lockstep) env->uni_t = -1;
 }
 static void note_budgets(w2a_env *env, int64_t cand, int sample_mode, int sticky) {
+  if (env->budget_bound != INT64_MAX) env->budget_bound_known = env->budget_bound;
   if (cand < 0 || (sample_mode == W2A_BUDGET_CENTERED && sticky)) { env->budget_bound = INT64_MAX; return; }  // unknown /
   if (sample_mode == W2A_BUDGET_CENTERED) cand = cand + cand / 2 + 1;        // a sticky centred budget is a random walk
   if (cand > env->budget_bound) env->budget_bound = cand;
@@ -195,6 +196,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.pk_hot = reinterpret_cast<uint2 *>((char *)h->st.stepc + align256(12 * (size_t)num_envs));
   h->st.pk_c = reinterpret_cast<uint2 *>((char *)h->st.pk_hot + align256(8 * (size_t)num_envs));
   h->pk_valid = 0; h->canon_valid = 1; h->uni_t = -1; h->uni_nd = -1; h->pk_t = 0; h->b0_max = 0; h->budget_bound = 0;
+  h->budget_bound_known = 0; h->graph_captured = 0;
   h->pk_static_ok = (t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22)) ? 1 : 0;
   h->status = status;
   h->has_autoreset = 0;
@@ -674,7 +676,16 @@ int w2a_query(w2a_env *env, int what) {
 
 int w2a_invalidate(w2a_env *env) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
+  if (env->budget_bound != INT64_MAX) env->budget_bound_known = env->budget_bound;
   env->pk_valid = 0; env->canon_valid = 1; env->uni_t = -1; env->perm_valid = 0; env->budget_bound = INT64_MAX;
+  return W2A_OK;
+}
+
+int w2a_set_budget_bound(w2a_env *env, int64_t bound) {
+  if (!env) return fail(W2A_ERR_ARG, "w2a_set_budget_bound: NULL handle");
+  if (bound < 0) { env->budget_bound = INT64_MAX; return W2A_OK; }
+  const int64_t prev = env->budget_bound != INT64_MAX ? env->budget_bound : env->budget_bound_known;
+  env->budget_bound = bound > prev ? bound : prev;  // budgets of earlier episodes may live on as sticky budgets
   return W2A_OK;
 }
 

@@ -38,7 +38,23 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
   // the day every env is on after this call, if the batch is (still) known to be in lock step: a plain step moves all
   // of them to the next day; the terminal step, an in-kernel autoreset or unknown state ends the knowledge
-  const int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
+  int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
+  // Stream capture (hipGraph): a captured step is replayed later without the host's bookkeeping being run again, so
+  // nothing that depends on it may be baked into the graph -- the packed variant takes the day as a kernel ARGUMENT.
+  // Under capture the canonical kernels run (they read the day from memory), and a handle that has ever been captured
+  // keeps to the canonical form for good (a replay advances days behind the host's back).
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      if (!env->canon_valid)
+        return fail(W2A_ERR_STATE, "w2a_step: stream capture started while the step state is in its packed lock-step form; "
+                                   "call w2a_get_state (or any entry point that reads the canonical state) before capturing");
+      env->graph_captured = 1;
+    } else {
+      (void)hipGetLastError();
+    }
+    if (env->graph_captured) uni_next = -1;
+  }
   if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
@@ -47,7 +63,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
     // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
     const bool packed = !given && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
-                        env->budget_bound <= 65535;
+                        env->budget_bound <= 65535 && !env->graph_captured;
     if (packed) {
       if (!env->pk_valid) {  // entering the packed form (once per episode): the canonical arrays are current
         hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);

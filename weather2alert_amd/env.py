@@ -376,6 +376,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._state.copy_(sd["state"])
         self._state[:256].copy_(hdr)
         _ffi.check(self._lib.w2a_invalidate(self._h), "w2a_invalidate")  # the state buffer changed behind the library
+        st = self.state()  # budgets of the restored episodes, incl. the sticky ones later resets may reuse
+        _ffi.check(self._lib.w2a_set_budget_bound(self._h, int(max(int(st["budget"].max()), int(st["sticky_budget"].max()), 0))),
+                   "w2a_set_budget_bound")
         self._obs.copy_(sd["obs"])
         self._final_return.copy_(sd["final_return"])
         self._reward.copy_(sd["reward"])
@@ -457,6 +460,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                            None if mask_t is None else mask_t.data_ptr(), obs_ptr, self._stream()),
                        "w2a_reset")
         self._keep = (t, tb, mask_t)  # keep inputs alive until the async launch has consumed them
+        # the budgets went over in device memory: tell the library their maximum (it holds budgets in 16 bits while the
+        # batch is in lock step and cannot see device values)
+        _ffi.check(self._lib.w2a_set_budget_bound(self._h, int(max(int(bud[sel].max()) if sel.any() else 0, 0))),
+                   "w2a_set_budget_bound")
         self._regroup()
 
     def _per_env(self, v, i):
