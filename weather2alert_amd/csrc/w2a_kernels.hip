@@ -462,7 +462,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: not available with corrected-semantics flags");
   PosteriorArgs a;
   memset(&a, 0, sizeof(a));
-  a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
+  a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.perm = env->perm; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
   a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
   ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);

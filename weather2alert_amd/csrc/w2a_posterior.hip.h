@@ -38,7 +38,8 @@ struct PosteriorArgs {
   DevTables tb;
   StateArrays st;
   const uint32_t *inv;   // [n] sorted position of every env (inverse of the env ids sorted by coefficient column)
-  uint4 *prep;           // [n] per-env record of the day in SORTED order (k_pm_prep -> k_posterior_mean*)
+  const uint32_t *perm;  // [n] env id at every sorted position
+  uint4 *prep;           // [n] per-env record of the day (k_pm_prep -> k_posterior_mean*), see W2A_PM_PREP_SCATTER
   const double *wd;      // [S * n_samples][2][32] coefficient rows as -log2(e) * W in fp64 (k_pm_wd)
   const uint4 *tiles;    // tile list of k_posterior_mean_v (k_tile_list)
   const uint32_t *n_tiles;
@@ -49,9 +50,18 @@ struct PosteriorArgs {
   int64_t n;
 };
 
-// Per-env record of the day, computed in ENV order (coalesced state / action reads, like phase A of k_step64) and
-// written to the env's position in the column order (one scattered 16-B store per env: stores do not stall), so the
-// reward kernel, which walks the envs in column order, reads its records coalesced with no dependent gather:
+// Per-env record of the day, computed in ENV order (coalesced state / action reads, like phase A of k_step64).
+// W2A_PM_PREP_SCATTER = 1 (default): written to the env's position in the column order (one scattered 16-B store per
+// env: stores do not stall), so the reward kernels, which walk the envs in column order, read their records coalesced
+// with no dependent gather. 0: written in env order (coalesced) and fetched as prep[perm[p]], a 16-B gather behind the
+// coalesced read of perm -- measured a wash at 1 M envs (pre-pass + reward kernel: int8 102.5 vs 101.1 us, vector
+// 171 vs 176 us; profiles/r03/pm_i8_variants.log): the gather costs what the scatter saved.
+#ifndef W2A_PM_PREP_SCATTER
+#define W2A_PM_PREP_SCATTER 1
+#endif
+// the record of sorted position `pos`
+#define PM_REC(a, pos) (W2A_PM_PREP_SCATTER ? (a).prep[(pos)] : (a).prep[(a).perm[(pos)]])
+// Record layout:
 // x = float index of the feature row, y = run-time fields packed (alert_lag1 bit 0, alert_streak bits 1..10,
 // alert_2wks bits 11..14, gate * actual bit 15, remaining_budget bits 16..31: budgets up to 65535, checked by the
 // host class), z = coefficient column, w = env id.
@@ -72,7 +82,7 @@ __global__ void k_pm_prep(const PosteriorArgs a) {
                         : (reinterpret_cast<const float *>(a.tb.X)[xrow + 30] > 0.5f ? 1u : 0u);
   const uint32_t rem = (uint32_t)min(max((int32_t)rt.z, 0), 65535);
   const uint32_t pk = (uint32_t)rt.x | ((uint32_t)rt.y << 1) | ((uint32_t)rt.w << 11) | (ga << 15) | (rem << 16);
-  a.prep[a.inv[e]] = make_uint4(xrow, pk, W_COL(c.c), e);
+  a.prep[W2A_PM_PREP_SCATTER ? a.inv[e] : e] = make_uint4(xrow, pk, W_COL(c.c), e);
   if (d.st_bits) atomicOr(a.status, (int)d.st_bits);
 }
 
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_posterior_mean(const PosteriorArgs
     float4 rt = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t ga = 0;
     if (pos < a.n) {
-      const uint4 pr = a.prep[pos];
+      const uint4 pr = PM_REC(a, pos);
       my_env = pr.w;
       xrow = pr.x;
       col = pr.z;
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(PMV_THREADS, 4) void k_posterior_mean_v(const Poste
   // ---- the row's record (coalesced) and its feature row of the day (requested at once, kept as f32 for the whole
   // kernel); rows past the end of the tile: feature row 0 (a valid address), never stored
   uint4 rec = make_uint4(0u, 0u, 0u, 0u);  // x feature row, y run-time fields, z column, w env id
-  if (tid < rows) rec = a.prep[tl.x + tid];
+  if (tid < rows) rec = PM_REC(a, tl.x + tid);
   float4 xf[KS];
   {
     const float4 *xp = a.tb.X + (rec.x >> 2);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
   if (W2A_PI8_PREFETCH_W) stage_load(0, min(PI8_NPAD, n_samples));
   // ---- lane = row: record and feature row of the day
   uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
-  if (tid < rows) rec = a.p.prep[tl.x + tid];
+  if (tid < rows) rec = PM_REC(a.p, tl.x + tid);
   float4 xf[ROWF / 4];
   {
     const float4 *xp = a.p.tb.X + (rec.x >> 2);
