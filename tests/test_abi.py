@@ -46,6 +46,31 @@ def test_host_only_entry_points(lib):
     assert lib.w2a_group_workspace_bytes(0, 10, 10) == 0 and lib.w2a_group_workspace_bytes(1000, 10, 10) >= 4 * 4 * 1000 + 10 * 10 * 512
     assert lib.w2a_group_by_column(None, None, 0, None) == -1
     assert lib.w2a_posterior_mean_reward(None, None, 0, None, None) == -1
+    # round-3 entry points: run-time choice of the posterior-mean kernel, bookkeeping queries, invalidation
+    assert lib.w2a_set_posterior_kernel(None, _ffi.PM_KERNELS["matrix_i8"]) == -1
+    assert lib.w2a_query(None, _ffi.Q_LOCKSTEP_DAY) == -1 and lib.w2a_invalidate(None) == -1
+    assert lib.w2a_set_budget_bound(None, 10) == -1 and b"NULL handle" in lib.w2a_last_error()
+    assert _ffi.PM_KERNELS == {"vector": 0, "matrix": 1, "matrix_i8": 2}
+
+
+def test_header_enums_match_binding():
+    """Numeric constants the Python binding hard-codes against the enums of include/w2a.h."""
+    text = open(os.path.join(ROOT, "include", "w2a.h")).read()
+
+    def enum(name):
+        m = re.search(r"\b" + name + r"\s*=?\s*(-?\d+)", text)  # enumerator `NAME = n` or `#define NAME n`
+        assert m, name
+        return int(m.group(1))
+
+    for name, val in (("W2A_STEP_AUTORESET", _ffi.STEP_AUTORESET), ("W2A_STEP_NO_OBS", _ffi.STEP_NO_OBS),
+                      ("W2A_STEP_CLASSIC", _ffi.STEP_CLASSIC), ("W2A_STEP_REWARD_GIVEN", _ffi.STEP_REWARD_GIVEN),
+                      ("W2A_STEP_WIDE", _ffi.STEP_WIDE), ("W2A_STEP_SKIP_FINISHED", _ffi.STEP_SKIP_FINISHED),
+                      ("W2A_STEP_UNPACKED", _ffi.STEP_UNPACKED), ("W2A_PM_VECTOR", 0), ("W2A_PM_MATRIX_F64", 1),
+                      ("W2A_PM_MATRIX_I8", 2), ("W2A_Q_LOCKSTEP_DAY", _ffi.Q_LOCKSTEP_DAY),
+                      ("W2A_Q_PACKED_ELIGIBLE", _ffi.Q_PACKED_ELIGIBLE), ("W2A_Q_PACKED_CURRENT", _ffi.Q_PACKED_CURRENT),
+                      ("W2A_Q_CANONICAL_CURRENT", _ffi.Q_CANONICAL_CURRENT), ("W2A_ABI_VERSION", _ffi.ABI_VERSION)):
+        assert enum(name) == val, name
+    assert enum("W2A_ABI_VERSION") == 12
 
 
 def test_ffi_struct_layout_matches_header():

@@ -152,3 +152,7 @@ def test_bench_defaults_follow_baseline_configs():
     cb = b.compulsory_bytes(29, True)
     assert cb["total"] == 161 and b.compulsory_bytes(29, False)["total"] == 45
     assert b.compulsory_bytes(29, True, packed=True)["total"] == 149  # 8 + 8 + 4 in, 8 + 4 + 1 + 116 out
+    cpus = b.usable_cpus()  # the CPU baseline runs one worker per CPU the process may really use
+    assert 1 <= cpus["usable"] <= cpus["os_cpu_count"] and cpus["usable"] <= cpus["affinity"]
+    assert cpus["cgroup_quota_cpus"] is None or cpus["usable"] <= max(1, int(cpus["cgroup_quota_cpus"] + 0.5))
+    assert isinstance(b.cpu_model(), str) and b.cpu_model()
