@@ -365,7 +365,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
             "host": {"sticky": list(self._sticky), "steps_in_episode": self._steps_in_episode,
                      "lockstep": self._lockstep, "reset_cfg": self._reset_cfg, "last_opts": dict(self._last_opts),
                      "needs_reset": self._needs_reset, "info_location": list(getattr(self, "_info_location", [])),
-                     "num_envs": self.num_envs, "env_gid0": self.env_gid0},
+                     "num_envs": self.num_envs, "env_gid0": self.env_gid0,
+                     # pm_kernel="auto" measures; a resumed run must compute rewards with the same kernel to stay
+                     # bit-exact with the run it continues (the kernels agree to ~1e-7, not to the last bit)
+                     "pm_kernel_choice": self.pm_kernel_choice},
         }
 
     def load_state_dict(self, sd: dict) -> None:
@@ -392,6 +395,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if self._reset_cfg is not None:
             with torch.cuda.device(self.device):
                 _ffi.check(self._lib.w2a_set_autoreset(self._h, *self._reset_cfg), "w2a_set_autoreset")
+        if self._pm and h.get("pm_kernel_choice") in _ffi.PM_KERNELS:  # continue on the kernel the checkpointed run used
+            self.pm_kernel_choice = h["pm_kernel_choice"]
+            _ffi.check(self._lib.w2a_set_posterior_kernel(self._h, _ffi.PM_KERNELS[self.pm_kernel_choice]),
+                       "w2a_set_posterior_kernel")
         self._regroup()  # posterior_mean: the restored episode tuples need their own column grouping
 
     # ------------------------------------------------------------------ reset
