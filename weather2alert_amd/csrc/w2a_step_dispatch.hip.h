@@ -30,12 +30,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_SKIP_FINISHED goes with W2A_STEP_REWARD_GIVEN (policy loops)");
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
-#if W2A_F64_SIGMOID
-  if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
-#else
-  // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
-  // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
-  const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
   // the day every env is on after this call, if the batch is (still) known to be in lock step: a plain step moves all
   // of them to the next day; the terminal step, an in-kernel autoreset or unknown state ends the knowledge
   int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
@@ -55,6 +49,12 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     }
     if (env->graph_captured) uni_next = -1;
   }
+#if W2A_F64_SIGMOID
+  if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
+#else
+  // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
+  // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
+  const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
   if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
