@@ -81,7 +81,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          "matrix_i8" (int8 matrix cores on exact fixed-point digits of both operands,
                          v_mfma_i32_16x16x64_i8 with int32 accumulation; csrc/w2a_posterior_i8.hip.h), or "auto"
                          (default): all are timed once on this env's own batch after the first reset and the fastest
-                         one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why).
+                         one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why). The kernels
+                         agree to ~1e-7, not to the last bit: name one for run-to-run bit reproducibility (a
+                         checkpoint carries the choice, so a resumed run continues on the same kernel).
     step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
                          64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
                          (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
