@@ -745,6 +745,9 @@ def main():
                          "traffic_unit": "fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts "
                                          "Infinity-Cache hits, so it is an upper bound on HBM bytes)",
                          "traffic_ratio": None if traffic is None else traffic["bytes_per_launch"] / (cb["total"] * n),
+                         # the rate at which the measured fabric bytes moved during this run's launches: what saturates
+                         # (a 1 GiB fill writes at ~6.9 TB/s on this chip, a float4 copy moves 6.29 TB/s)
+                         "fabric_gbs": None if traffic is None else traffic["bytes_per_launch"] / per_launch_s / 1e9,
                          "traffic_source": None if traffic is None else
                          {k: traffic.get(k) for k in ("read_bytes_per_launch", "write_bytes_per_launch",
                                                       "kernel_avg_us", "src_sha", "commit", "profile")},
