@@ -468,6 +468,20 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
                           "unit": "env-steps/s", "note": "rollout(): threshold policy, one launch per 153-day episode "
                           "(k_pm_rollout_i8 / k_pm_rollout), grouping by column included"}
         ea.close()
+        # matrix-core counters of the same kernels from their own rocprofv3 --pmc passes (profiles/r03/, collected by
+        # tools/gpu_session.sh prof:configs2:pm_<kernel>; a PMC pass cannot run inside this process)
+        for name in res["kernels"]:
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r03", f"pmc_configs2_pm_{name}.json")))
+                e = next(v for k, v in pj["pmc"].items() if "k_posterior_mean" in k)
+                busy = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+                res["kernels"][name]["rocprof"] = {
+                    "kernel_avg_us": e.get("avg_us"), "SQ_INSTS_MFMA": e.get("SQ_INSTS_MFMA"),
+                    "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_INSTS_VALU": e.get("SQ_INSTS_VALU"),
+                    "mfma_busy_frac": busy / (1024 * e["avg_us"] * 2400.0) if e.get("avg_us") else None,
+                    "note": "busy cycles / (1024 SIMDs x kernel time x 2.4 GHz); workload configs2, 1 048 576 envs"}
+            except Exception:  # noqa: BLE001
+                pass
         best = min(res["kernels"], key=lambda k: res["kernels"][k]["us_per_step"])
         res.update(us_per_step=res["kernels"][best]["us_per_step"], value=res["kernels"][best]["value"], fastest=best,
                    vector_peak_tflops_fp64=78.6,
