@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 12
+#define W2A_ABI_VERSION 13
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -268,6 +268,17 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
  * used. */
 size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows);
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Optional, speed only: let w2a_rollout compute the table-sourced part of both logits -- 27 of their 30 terms, which do
+ * not depend on the agent's actions -- for all envs of a (county, year) and 16 days at a time on the int8 matrix cores
+ * (exact fixed-point digits, int32 accumulation; csrc/w2a_rollout_mfma.hip.h), leaving 3 + 3 fp64 FMAs per env-day on
+ * the vector ALU instead of 30 + 30. Call after w2a_rollout_order of the episode (it lists the tiles of envs sharing a
+ * feature row from that order and, once per table, builds a digit table of W in the workspace). Used by w2a_rollout
+ * while the handle knows the batch to be in lock step and no corrected-semantics flag is set; results agree with the
+ * other rollout kernels to the accuracy of the fixed point (returns within ~1e-6 relative), integers identical.
+ * workspace: caller-owned, w2a_rollout_mfma_workspace_bytes(...) bytes, 256-B aligned, alive while w2a_rollout is used. */
+size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples);
+int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* w2a_rollout with the posterior-mean reward (w2a_posterior_mean_reward's value every day), whole episode in one launch:
  * same arguments and outputs as w2a_rollout; needs w2a_group_by_column after the last reset. Built on the kernel selected

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 12
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 13
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
@@ -70,7 +70,7 @@ def test_header_enums_match_binding():
                       ("W2A_Q_PACKED_ELIGIBLE", _ffi.Q_PACKED_ELIGIBLE), ("W2A_Q_PACKED_CURRENT", _ffi.Q_PACKED_CURRENT),
                       ("W2A_Q_CANONICAL_CURRENT", _ffi.Q_CANONICAL_CURRENT), ("W2A_ABI_VERSION", _ffi.ABI_VERSION)):
         assert enum(name) == val, name
-    assert enum("W2A_ABI_VERSION") == 12
+    assert enum("W2A_ABI_VERSION") == 13
 
 
 def test_ffi_struct_layout_matches_header():

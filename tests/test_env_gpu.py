@@ -306,12 +306,14 @@ def test_packed_lockstep_state_equals_canonical_state(dev):
             same_state()  # read-back converts to the canonical form; the packed one stays valid
             assert q(A, _ffi.Q_PACKED_CURRENT) == 1 and q(A, _ffi.Q_CANONICAL_CURRENT) == 1
     assert torch.equal(A._final_return, B._final_return)
-    # a rollout leaves lock step as far as the handle knows: canonical kernel from here to the next full reset
+    # a rollout works on the canonical form and keeps the batch in lock step (every env runs the same days): the
+    # handle knows the new day and the next step() packs again
     pol = dict(kind="bernoulli", p=0.2, seed=4)
     ra, rb = A.rollout(pol, n_steps=10), B.rollout(pol, n_steps=10)
-    assert torch.equal(ra["alerts"], rb["alerts"]) and torch.equal(ra["return"], rb["return"])
+    assert torch.equal(ra["alerts"], rb["alerts"]) and torch.equal(ra["return"], rb["return"])  # same rollout kernel
+    assert not A.packed_state and q(A, _ffi.Q_LOCKSTEP_DAY) == 50
     both(torch.ones(n, dtype=torch.int32, device=dev))
-    assert not A.packed_state and q(A, _ffi.Q_LOCKSTEP_DAY) == -1
+    assert A.packed_state and q(A, _ffi.Q_LOCKSTEP_DAY) == 51
     same_state()
     A.reset(seed=13)
     B.reset(seed=13)
@@ -726,6 +728,70 @@ def test_rollout_visiting_order_does_not_change_results(dev):
             assert torch.equal(sa[k], sb[k]), k
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("kind", ["bernoulli", "threshold", "threshold_lag0", "table", "always"])
+def test_matrix_core_rollout_matches_vector_rollout_and_oracle(dev, kind):
+    """rollout_mfma=True: the 27 action-independent terms of both logits come from int8 MFMAs over (envs of a feature
+    row) x (16 days) tiles, the 3 run-time terms are added per day in fp64. Against k_rollout64 on the same episodes:
+    alerts, over-budget attempts, day bitmaps and integer state identical, returns within the fixed point's accuracy;
+    and against the oracle's policy loop. Partial rollouts (the lock-step day is tracked through them), explicit steps in
+    between, the next episode after the lock-step autoreset; tiles of every fill (n not a multiple of 64, a few envs
+    per feature row up to several tiles per row)."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=12, years=[2006, 2007], n_samples=6, seed=57, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n, gid0 = 3000 + 37, 500  # 24 feature rows: ~125 envs each = 2 tiles per row, the last one partial
+    kw = dict(tables=ct, device=dev, env_gid0=gid0, similar_climate_counties=True)
+    A = HeatAlertVecEnv(n, rollout_mfma=True, **kw)
+    B = HeatAlertVecEnv(n, rollout_mfma=False, **kw)
+    A.reset(seed=21, options={"budget": 9})
+    B.reset(seed=21, options={"budget": 9})
+    st = _oracle_for_env(A, V)
+    rng = np.random.default_rng(0)
+    table = (rng.random((ct.T, 5)) < 0.3).astype(np.uint8)
+    pol = {"always": dict(kind="always"), "bernoulli": dict(kind="bernoulli", p=0.15, seed=99),
+           "threshold": dict(kind="threshold", feature="heat_qi", threshold=0.8, require_budget=True),
+           "threshold_lag0": dict(kind="threshold", feature="heat_qi", threshold=0.7, lag=0),
+           "table": dict(kind="table", table=table)}[kind]
+    opol = dict(pol, col=ct.columns.index("heat_qi"))
+    draw = (lambda i, t: O.devrng_policy_uniform(99, gid0 + i, int(st["episode_no"][i]), t)) if kind == "bernoulli" else None
+
+    def check(steps):
+        oa, ob = A.rollout(pol, n_steps=steps, alert_mask=True), B.rollout(pol, n_steps=steps, alert_mask=True)
+        ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, opol, steps if steps else ct.T, draw)
+        for k in ("alerts", "attempts_over_budget", "alert_days", "attempt_days", "done"):
+            assert torch.equal(oa[k], ob[k]), k
+        np.testing.assert_array_equal(oa["alerts"].cpu().numpy(), al_o)
+        np.testing.assert_array_equal(oa["attempts_over_budget"].cpu().numpy(), ov_o)
+        np.testing.assert_array_equal(oa["alert_days"].cpu().numpy(), days_o)
+        torch.testing.assert_close(oa["return"], ob["return"], rtol=3e-6, atol=3e-5)
+        np.testing.assert_allclose(oa["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+        return oa
+
+    check(21)   # starts on day 0, ends inside a 16-day chunk
+    check(16)   # a whole chunk starting on day 21
+    for _ in range(3):  # explicit steps: the handle keeps track of the day
+        a = (rng.random(n) < 0.2).astype(np.int32)
+        A.step(torch.as_tensor(a, device=dev))
+        B.step(torch.as_tensor(a, device=dev))
+        V.step(a)
+    out = check(None)  # the rest of the episode
+    assert out["done"].all() and (out["first_day"] == 40).all()
+    sa, sb = A.state(), B.state()
+    for k in sa:  # the lock-step autoreset has started the next episode on both
+        if k == "episode_return":
+            torch.testing.assert_close(sa[k], sb[k], rtol=3e-6, atol=3e-5)
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+    assert (sa["episode_no"] == 1).all()
+    st = _oracle_for_env(A, V)
+    check(None)
+    assert A.check_status() == 0
+    A.close()
+    B.close()
 
 
 def test_partial_rollouts_report_done_from_the_finished_bit(dev):

@@ -14,10 +14,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 sd = synth.make_synth("linear", years=list(range(2006, 2017)), n_samples=100, seed=0, extra_confounder_fips=60)
 ct = tables.compile_from_synth(sd)
 # bench_rollout.py [num_envs [iid|sorted|iid_unordered]]; *_unordered = rollout_order=False (envs visited by index)
-orders = (sys.argv[2],) if len(sys.argv) > 2 else ("iid", "iid_unordered", "sorted")
+# iid = visiting order + matrix-core kernel (k_rollout_mfma); iid_vector = visiting order, k_rollout64 (rollout_mfma=False)
+orders = (sys.argv[2],) if len(sys.argv) > 2 else ("iid", "iid_vector", "iid_unordered", "sorted")
 for order in orders:
     env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, episode_order=order.split("_")[0],
-                          rollout_order=not order.endswith("_unordered"))
+                          rollout_order=not order.endswith("_unordered"), rollout_mfma=not order.endswith("_vector"))
     env.reset(seed=0)
     pol = dict(kind="threshold", feature="heat_qi", threshold=0.9, require_budget=True)
     env.rollout(pol)

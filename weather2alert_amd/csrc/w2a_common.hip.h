@@ -181,6 +181,16 @@ struct w2a_env {
   const uint32_t *colflag;
   const float *xs;
   const void *xmax_ws;   // workspace whose slot maxima (once-per-table scan) are valid
+  // matrix-core rollout (w2a_rollout_mfma.hip.h): tile list by feature row + digit table of W, in its own workspace
+  const uint32_t *order_cursor;  // the counting sort's cursors after the scatter (end of every feature row's segment)
+  const void *rm_ws;             // workspace whose W digit table is built
+  const uint4 *rm_tiles;
+  const uint32_t *rm_n_tiles;
+  const uint32_t *rm_wq;
+  const float *rm_wscale;
+  const uint32_t *rm_rowflag;
+  const float *rm_xs;
+  int rm_valid;                  // the tile list belongs to the current episode's visiting order
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
   // which form of the per-env step state is current (see StateArrays): the canonical arrays, the lock-step mirror,

@@ -43,6 +43,7 @@
 #include "w2a_reset.hip.h"
 #include "w2a_rollout.hip.h"
 #include "w2a_rollout_i8.hip.h"
+#include "w2a_rollout_mfma.hip.h"
 #include "w2a_sort.hip.h"
 
 // ----------------------------------------------------------------------------------------
@@ -71,6 +72,9 @@ static void launch_pm_rollout(int kind, bool masks, unsigned grid, hipStream_t s
   }
 }
 
+#ifndef W2A_ROLLOUT_MFMA
+#define W2A_ROLLOUT_MFMA 1  // 1: w2a_rollout uses k_rollout_mfma when w2a_rollout_mfma_prepare has run for the episode (A/B)
+#endif
 #ifndef W2A_ROLLOUT_WIDE
 #define W2A_ROLLOUT_WIDE 1  // 1: lane = env day loop (k_rollout64) when a visiting order is set; 0: always 4 lanes per env
 #endif
@@ -206,6 +210,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->perm_valid = 0;
   h->pm_kernel = W2A_PM_VECTOR;
   h->xmax_ws = nullptr;
+  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -251,6 +256,7 @@ static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   // and w2a_observe read the rest as well
   if (a.mask || a.from_tuples == 2) ensure_canonical(env, (hipStream_t)stream);
   if (a.from_tuples != 2) {
+    env->rm_valid = 0;  // new episodes: the feature-row tile list of the matrix-core rollout is stale
     env->canon_valid = 1;
     canonical_modified(env);
     if (!a.mask && env->uni_nd > 0) env->uni_t = 0;  // every env on day 0 of an episode of the one length there is
@@ -340,6 +346,7 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   const unsigned blocks = (unsigned)((n + 255) / 256);
   ensure_canonical(env, s);
   canonical_modified(env, true);  // a relabelling: the batch stays in lock step
+  env->rm_valid = 0;
   hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
@@ -534,6 +541,60 @@ int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   hipLaunchKernelGGL(k_order_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, cnt, order, env->n);
   HIP_TRY(hipGetLastError());
   env->order = order;
+  env->order_cursor = cnt;
+  env->rm_valid = 0;
+  return W2A_OK;
+}
+
+// ---- matrix-core rollout: workspace, preparation -------------------------------------------------------------------
+static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 63) / 64) + (size_t)rows; }
+size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples) {
+  if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0) return 0;
+  const size_t w_rows = (size_t)S * n_samples * 2;
+  return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 + 2 * align256(4 * (size_t)table_rows) +
+         align256(w_rows * ROWF * 4) + align256(w_rows * 4) + align256(2 * w_rows) + 3 * 256;
+}
+
+int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_mfma_prepare: NULL argument");
+  const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
+  if (workspace_bytes < w2a_rollout_mfma_workspace_bytes(env->n, rows, env->tb.S, env->tb.n_samples))
+    return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace too small");
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace must be 256-B aligned");
+  if (!env->order || !env->order_cursor)
+    return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: call w2a_rollout_order for this episode first");
+  const size_t w_rows = (size_t)env->tb.S * env->tb.n_samples * 2;
+  char *p = (char *)workspace;
+  uint4 *tiles = (uint4 *)p;            p += align256(16 * rm_max_tiles(env->n, rows));
+  uint32_t *n_tiles = (uint32_t *)p;    p += 256;
+  uint32_t *seg_start = (uint32_t *)p;  p += align256(4 * (size_t)rows);
+  uint32_t *seg_end = (uint32_t *)p;    p += align256(4 * (size_t)rows);
+  uint32_t *wq = (uint32_t *)p;         p += align256(w_rows * ROWF * 4);
+  float *wscale = (float *)p;           p += align256(w_rows * 4);
+  uint32_t *rowflag = (uint32_t *)p;    p += align256(2 * w_rows);
+  uint32_t *xmax_bits = (uint32_t *)p;  p += 256;
+  uint32_t *bmax = (uint32_t *)p;       p += 256;
+  float *xs = (float *)p;               p += 256;
+  hipStream_t s = (hipStream_t)stream;
+  if (env->rm_ws != workspace) {  // once per table and workspace: slot scales and the digit table of W
+    HIP_TRY(hipMemsetAsync(xmax_bits, 0, 512, s));  // slot maxima and the (unused here) budget maximum
+    HIP_TRY(hipMemsetAsync(rowflag, 0, 2 * w_rows, s));
+    hipLaunchKernelGGL(k_pi8_slot_max, dim3(2048), dim3(256), 0, s, env->tb.X,
+                       (int64_t)env->tb.T * env->tb.S_w * env->tb.Y * (ROWF / 4), xmax_bits);
+    hipLaunchKernelGGL(k_pi8_scales, dim3(1), dim3(64), 0, s, xmax_bits, bmax, env->tb.T, xs);
+    hipLaunchKernelGGL(k_rm_wq, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, wq, wscale, rowflag);
+    HIP_TRY(hipGetLastError());
+    env->rm_ws = workspace;
+  }
+  // tiles of <= 64 consecutive positions of the visiting order that share one feature row
+  hipLaunchKernelGGL(k_rm_bounds, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, env->order_cursor, (int32_t)rows,
+                     seg_start, seg_end);
+  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, seg_start, seg_end, (int32_t)rows, tiles, n_tiles, 64u);
+  HIP_TRY(hipGetLastError());
+  env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq; env->rm_wscale = wscale; env->rm_rowflag = rowflag;
+  env->rm_xs = xs;
+  env->rm_valid = 1;
   return W2A_OK;
 }
 
@@ -563,10 +624,24 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   a.ret_snapshot = ret_snapshot;
   a.order = env->order;
   hipStream_t s = (hipStream_t)stream;
+  const int32_t lockstep_day = env->uni_t;  // -1: the handle does not know every env to be on the same day
   ensure_canonical(env, s);
-  canonical_modified(env);
+  canonical_modified(env, true);
+  // a batch in lock step stays in lock step: every env runs the same n_steps days, or all of them reach their last day
+  env->uni_t = (lockstep_day >= 0 && lockstep_day + n_steps < env->uni_nd) ? lockstep_day + n_steps : -1;
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
+  if (env->rm_valid && a.order && !env->tb.fixes && lockstep_day >= 0 && W2A_ROLLOUT_MFMA) {
+    // the table-sourced part of the logits on the int8 matrix cores (w2a_rollout_mfma.hip.h): needs the episode's
+    // feature-row tile list (w2a_rollout_mfma_prepare) and a batch in lock step
+    RmArgs ra;
+    ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.wscale = env->rm_wscale;
+    ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs;
+    const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
+    hipLaunchKernelGGL(k_rollout_mfma, dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * RM_WAVES), 0, s, ra);
+    HIP_TRY(hipGetLastError());
+    return W2A_OK;
+  }
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
@@ -608,8 +683,12 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   a.ret_snapshot = ret_snapshot;
   pa.perm = env->perm; pa.tiles = env->tiles; pa.n_tiles = env->n_tiles; pa.wd = env->wd;
   hipStream_t s = (hipStream_t)stream;
-  ensure_canonical(env, s);
-  canonical_modified(env);
+  {
+    const int32_t lockstep_day = env->uni_t;
+    ensure_canonical(env, s);
+    canonical_modified(env, true);
+    env->uni_t = (lockstep_day >= 0 && lockstep_day + n_steps < env->uni_nd) ? lockstep_day + n_steps : -1;
+  }
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (i8) {

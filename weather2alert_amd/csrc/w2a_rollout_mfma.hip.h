@@ -1,0 +1,297 @@
+// w2a_rollout_mfma.hip.h -- k_rollout_mfma: the on-device policy rollout (sampled reward, env.py:238-262 per day) with the
+// table-sourced part of both logits on the int8 matrix cores.
+// Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
+#ifndef W2A_ROLLOUT_MFMA_HIP_H
+#define W2A_ROLLOUT_MFMA_HIP_H
+
+// k_rollout64 spends three quarters of its vector instructions on the two 30-term fp64 dot products of every env-day.
+// 27 of the 30 terms do not depend on what the agent did: for the envs of one (county, year) -- which the visiting order
+// (w2a_rollout_order) already puts side by side -- they are
+//      Z[env][day][head] = sum_{k table-sourced, bias} W[env's (column, draw)][head][k] * X[(county, year)][day][k],
+// a GEMM with M = envs of the feature row, N = days, K = 32 slots. Only alert_lag1, alert_streak and remaining_budget
+// (slots 24..26) follow the agent's actions; they are added per day in fp64. The GEMM runs on v_mfma_i32_16x16x64_i8 with
+// the exact fixed-point digits of w2a_posterior_i8.hip.h -- here the ENV rows carry the coefficient digits (A operands
+// P = (W0 | W1), Q = (W2 | W3), gathered once per launch from a digit table of W built once per handle, run-time slots
+// zeroed so that they do not inflate the row's scale) and the DAY columns carry the feature digits
+// (B_m = (X_m | X_{m-1}), converted per 16-day chunk from the float32 rows of the (county, year)). Same six MFMAs per
+// 16 x 16 tile, same a-priori bound |dz| <= 1.5 * 2^(ew - 23.4); coefficient rows outside the fixed-point range
+// (rowflag) make their env compute the plain fp64 dot product per day instead (per lane, rare).
+//
+// One wave = one tile of <= 64 envs of ONE feature row (tile list of w2a_rollout_mfma_prepare), lock step required (every
+// env on the same day: the handle's bookkeeping, else k_rollout64 serves the call). Per 16-day chunk: 128 (day, slot
+// group) conversions -> the chunk's feature digits in the wave's LDS; 4 row tiles x 2 heads x 6 MFMAs; the int32 sums ->
+// f32 logit parts -> LDS [env][day][head]; then 16 days of k_rollout64's day loop with 3 + 3 fp64 FMAs in place of
+// 30 + 30. Outputs, RNG streams and state are those of k_rollout64 (indexed by env id).
+#define RM_WAVES 4
+#define RM_ZSTRIDE 33  // floats per env of the logit-part image: 16 days x 2 heads + 1 pad (lane = env reads, bank-conflict free)
+
+struct RmArgs {
+  RolloutArgs r;
+  const uint4 *tiles;       // (first position in the visiting order, envs, feature row, 0)
+  const uint32_t *n_tiles;
+  const uint32_t *wq;       // [S * n_samples * 2][32] int8 digit planes of W, run-time slots zeroed
+  const float *wscale;      // [S * n_samples * 2]  2^(ew - 20)
+  const uint32_t *rowflag;  // [S * n_samples]  1 = a head of this coefficient row is outside the fixed-point range
+  const float *xs;          // [64] slot scales
+};
+
+// coefficient rows -> digit planes for this kernel: slots 24..27 (run-time fields) zeroed, scale in natural units,
+// one flag per (column, draw)
+__global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t *wq, float *wscale, uint32_t *rowflag) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float w[ROWF];
+  float m = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ROWF; ++k) {
+    w[k] = (k >= 24 && k <= 27) ? 0.0f : W[r * ROWF + k] * xs[ROWF + k];
+    m = fmaxf(m, fabsf(w[k]));
+  }
+  int ew = 0;
+  if (m > 0.0f) (void)frexpf(m, &ew);
+  if (ew > W2A_PI8_EW_MAX) atomicOr(&rowflag[r >> 1], 1u);
+  const float s = ldexpf(1.0f, 30 - ew);
+  uint32_t planes[4][8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    uint32_t d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d[c] = pi8_digits(__float2int_rn(w[4 * g + c] * s));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int sh = 8 * (3 - p);
+      planes[p][g] = ((d[0] >> sh) & 255u) | (((d[1] >> sh) & 255u) << 8) | (((d[2] >> sh) & 255u) << 16) | (((d[3] >> sh) & 255u) << 24);
+    }
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(wq + r * ROWF);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    dst[2 * p] = make_uint4(planes[p][0], planes[p][1], planes[p][2], planes[p][3]);
+    dst[2 * p + 1] = make_uint4(planes[p][4], planes[p][5], planes[p][6], planes[p][7]);
+  }
+  wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
+}
+// feature-row segments of the visiting order from the counting sort's cursors (cursor[r] = end of row r after the scatter)
+__global__ void k_rm_bounds(const uint32_t *cursor, int32_t rows, uint32_t *start, uint32_t *end) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  start[r] = r ? cursor[r - 1] : 0u;
+  end[r] = cursor[r];
+}
+
+__global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs ra) {
+  const RolloutArgs &a = ra.r;
+  __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
+  __shared__ float sZ[RM_WAVES][64][RM_ZSTRIDE];                                      // logit parts [env][day * 2 + head]
+  __shared__ float sSc[RM_WAVES][64][2];                                              // row scales [env][head]
+  __shared__ float sDay[RM_WAVES][16][2];  // per day of the chunk: gate flag (slot 30), the threshold policy's feature
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c16 = lane & 15;
+  const uint32_t n_tiles = *ra.n_tiles;
+  const uint32_t tile = logical_block(blockIdx.x, gridDim.x >> 3) * RM_WAVES + wave;
+  if (tile >= n_tiles) return;  // whole wave; only wave-level synchronisation below
+  const uint4 tl = ra.tiles[tile];
+  const int count = (int)__builtin_amdgcn_readfirstlane(tl.y);
+  const uint32_t frow = __builtin_amdgcn_readfirstlane(tl.z);
+  const bool valid = lane < count;
+  const uint32_t e = a.order[tl.x + (valid ? lane : 0)];
+  uint4 c2, hot;
+  load_step_state(a.st, e, c2, hot);
+  const uint4 cold = load_cold(a.st, e);
+  uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
+  uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
+  const uint32_t ndays = D1_NDAYS(hot.y);
+  const int32_t budget = (int32_t)hot.w;
+  bool fin = D1_FIN(hot.y) != 0;
+  float ret_total = __uint_as_float(hot.z);
+  const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
+  const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
+  const float *Wf = reinterpret_cast<const float *>(a.tb.W) + (size_t)wrow * (2 * ROWF);
+  const bool exact = ra.rowflag[wrow] != 0u;  // this env's coefficient row is outside the fixed-point range
+  // the three run-time coefficients of both heads (slots 24, 25, 26; slot 27 has none in the faithful semantics, Q1 --
+  // kept anyway so that a coefficient there is honoured)
+  const double wl_b = Wf[24], ws_b = Wf[25], wr_b = Wf[26], wa_b = Wf[27];
+  const double wl_e = Wf[ROWF + 24], ws_e = Wf[ROWF + 25], wr_e = Wf[ROWF + 26], wa_e = Wf[ROWF + 27];
+  sSc[wave][lane][0] = ra.wscale[(size_t)wrow * 2];
+  sSc[wave][lane][1] = ra.wscale[(size_t)wrow * 2 + 1];
+  // A operands: row tile m, lane (c16, q) holds 16 slots of one plane of env 16 m + c16 (its coefficient digits)
+  pi8_v4i P[4][2], Q[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const uint32_t wr = (uint32_t)__shfl((int)wrow, 16 * m + c16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t *row = ra.wq + ((size_t)wr * 2 + h) * ROWF;
+      P[m][h] = *reinterpret_cast<const pi8_v4i *>(row + 4 * q);
+      Q[m][h] = *reinterpret_cast<const pi8_v4i *>(row + 16 + 4 * q);
+    }
+  }
+  const float *Xf = reinterpret_cast<const float *>(a.tb.X);
+  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+  const int32_t kind = a.pol.kind;
+  float ret = 0.0f;
+  int32_t alerts = 0, over = 0;
+  uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
+  uint32_t att_word = 0, att_idx = 0xFFFFFFFFu;
+  float snap = 0.0f;
+  bool snapped = false;
+  // threshold policy: the lagging observation (row of day t - 1, Q6) is carried from day to day; obs_lag = 0 reads today's
+  const int pol_quad = kind == W2A_POLICY_THRESHOLD ? (a.pol_slot >> 2) : -1, pol_comp = a.pol_slot & 3;
+  float feat = 0.0f;
+  if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t > 0)
+    feat = Xf[((size_t)((t - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
+  bool active = !fin && valid;
+  const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);  // lock step: every env of the batch is on this day
+  int steps_left = a.n_steps;
+  for (uint32_t c0 = t_first; steps_left > 0 && __any(active); c0 += 16) {
+    // ---- feature digits of days c0 .. c0 + 15 of this (county, year): lane = (day, two slot groups)
+    {
+      const int j = lane >> 2, g0 = (lane & 3) * 2;
+      const uint32_t day = min(c0 + (uint32_t)j, (uint32_t)a.tb.T - 1u);
+      const float4 *xp = a.tb.X + ((size_t)day * rows_per_day + frow) * (ROWF / 4);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = g0 + gg;
+        const float4 v = xp[g];
+        uint32_t d[4], o[4];
+        d[0] = pi8_digits((int32_t)(v.x * ra.xs[4 * g]));
+        d[1] = pi8_digits((int32_t)(v.y * ra.xs[4 * g + 1]));
+        d[2] = pi8_digits((int32_t)(v.z * ra.xs[4 * g + 2]));
+        d[3] = pi8_digits((int32_t)(v.w * ra.xs[4 * g + 3]));
+        pi8_planes(d, o);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = o[p];
+        // what the day loop reads of the row itself: the tile's envs share it, so it is staged here once per chunk
+        // instead of being fetched by every lane on every day (a dependent global load per day: the loop's latency)
+        if (g == GATE_QUAD) sDay[wave][j][0] = v.z;
+        if (g == pol_quad) sDay[wave][j][1] = pol_comp == 0 ? v.x : pol_comp == 1 ? v.y : pol_comp == 2 ? v.z : v.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- B operands (day column c16): B_m = (X_m | X_{m-1})
+    pi8_v4i B[4];
+    {
+      const uint32_t *x = sXd[wave][c16];
+      const int half = 4 * (q & 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int plane = q < 2 ? m : m - 1;
+        const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(x + 8 * max(plane, 0) + half);
+        B[m] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
+      }
+    }
+    // ---- 4 row tiles x 2 heads: six MFMAs each, int32 sums -> f32 logit part -> sZ[env][day][head]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (16 * m >= count) continue;  // wave-uniform
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const pi8_v4i zero = {0, 0, 0, 0};
+        pi8_v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[0], zero, 0, 0, 0);
+        pi8_v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[1], zero, 0, 0, 0);
+        pi8_v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[2], zero, 0, 0, 0);
+        pi8_v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[3], zero, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Q[m][h], B[0], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Q[m][h], B[1], a3, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // accumulator row 4 q + j of the row tile = env, column c16 = day
+          const int er = 16 * m + 4 * q + j;
+          const float sc = sSc[wave][er][h];
+          const float u = (float)(a0[j] * 256 + a1[j]);
+          const float v = (float)(a2[j] * 256 + a3[j]);
+          sZ[wave][er][c16 * 2 + h] = fmaf(v, sc * 1.52587890625e-05f, u * sc);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ)
+    const int chunk = min(16, steps_left);
+    for (int dd = 0; dd < chunk; ++dd) {
+      if (!__any(active)) break;
+      const float today = sDay[wave][dd][1], gate = sDay[wave][dd][0];  // lock step: t = c0 + dd in every live lane
+      const int32_t act = policy_action(kind, a.pol, pstream, t, budget - (int32_t)used,
+                                        (a.pol.obs_lag && t > 0) ? feat : today);
+      const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
+      const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
+      const uint32_t used2 = used + actual;
+      const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
+      const uint32_t day_row = t * rows_per_day + frow;
+      const double f_lag = (t > 0) ? (double)actual : 0.0, f_streak = (double)streak;
+      const double f_rem = (double)(budget - (int32_t)used2), f_a2w = (double)__popc(hist2);
+      double zb, ze;
+      if (exact) {  // plain fp64 dot products for a coefficient row outside the fixed-point range
+        zb = 0.0; ze = 0.0;
+        const float *xr = Xf + (size_t)day_row * ROWF;
+        for (int k = 0; k < ROWF; ++k) {
+          if (k >= 24 && k <= 27) continue;
+          const double xk = (double)xr[k];
+          zb = fma(xk, (double)Wf[k], zb);
+          ze = fma(xk, (double)Wf[ROWF + k], ze);
+        }
+      } else {
+        zb = (double)sZ[wave][lane][dd * 2];
+        ze = (double)sZ[wave][lane][dd * 2 + 1];
+      }
+      zb = fma(f_lag, wl_b, zb); zb = fma(f_streak, ws_b, zb); zb = fma(f_rem, wr_b, zb); zb = fma(f_a2w, wa_b, zb);
+      ze = fma(f_lag, wl_e, ze); ze = fma(f_streak, ws_e, ze); ze = fma(f_rem, wr_e, ze); ze = fma(f_a2w, wa_e, ze);
+      if (!(gate > 0.5f)) ze = -__builtin_inf();
+      const float r = reward_from_logits(zb, ze, actual);
+      if (active) {
+        const bool done = (t + 1 >= ndays);
+        ret += r;
+        ret_total += r;
+        alerts += (int32_t)actual;
+        over += (act == 1 && atb_s) ? 1 : 0;
+        if (a.alert_mask && actual) {
+          const uint32_t wi = t >> 5;
+          if (wi != mask_idx) {
+            if (mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+              a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+            mask_idx = wi;
+            mask_word = 0;
+          }
+          mask_word |= 1u << (t & 31);
+        }
+        if (a.attempt_mask && act == 1) {
+          const uint32_t wi = t >> 5;
+          if (wi != att_idx) {
+            if (att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+              a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+            att_idx = wi;
+            att_word = 0;
+          }
+          att_word |= 1u << (t & 31);
+        }
+        if ((done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
+        used = used2; hist = hist2; last = actual; atb = atb_s;
+        if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
+        else { fin = true; active = false; }
+        feat = today;
+      }
+    }
+    steps_left -= chunk;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // sXd / sZ are rewritten by the next chunk
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (valid) {
+    store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
+                                  __float_as_uint(ret_total), (uint32_t)budget));
+    if (a.ret_out) a.ret_out[e] = ret;
+    if (a.alerts_out) a.alerts_out[e] = alerts;
+    if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
+    if (a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+      a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
+    if (a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+      a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
+    if (a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
+    if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
+  }
+}
+
+#endif  // W2A_ROLLOUT_MFMA_HIP_H

@@ -71,6 +71,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
     rollout_order        True (default): rollout() lets the kernel visit the envs in the order of their feature rows
                          (w2a_rollout_order, one sort per episode); outputs are indexed by env id either way.
+    rollout_mfma         True (default): with that order, a batch in lock step and faithful semantics rollout() computes
+                         the 27 action-independent terms of both logits for all envs of a (county, year) and 16 days at a
+                         time on the int8 matrix cores (exact fixed-point digits, csrc/w2a_rollout_mfma.hip.h) and only
+                         the 3 run-time terms per day in fp64. Integers identical, returns within ~1e-6 relative.
     reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
                          "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
@@ -125,6 +129,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         rollout_order: bool = True,
         pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "auto",
+        rollout_mfma: bool = True,
     ):
         self._lib = _ffi.load()
         self.device = torch.device(device)
@@ -177,6 +182,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self.pm_kernel_choice = None if pm_kernel == "auto" else pm_kernel  # decided after the first reset
         self.pm_kernel_timing_us: dict = {}
         self.rollout_order = bool(rollout_order)  # rollout() visits the envs in feature-row order (speed only; A/B)
+        # rollout(): the table-sourced part of the logits on the int8 matrix cores (needs the visiting order, a batch in
+        # lock step and faithful semantics; speed only; A/B)
+        self.rollout_mfma = bool(rollout_mfma)
+        self._mfma_ws = None
         self.pm_rollout_kernel = True  # posterior_mean rollouts in one launch when possible (False: per-day launches)
         self._order_stale = True
         if episode_order not in ("iid", "sorted"):
@@ -697,6 +706,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 _ffi.check(self._lib.w2a_rollout_order(self._h, self._order_ws.data_ptr(), self._order_ws.numel(),
                                                        self._stream()), "w2a_rollout_order")
                 self._order_stale = False
+                if self.rollout_mfma and not (self.fixes - {"budget"}):
+                    if self._mfma_ws is None:
+                        self._mfma_ws = torch.empty(self._lib.w2a_rollout_mfma_workspace_bytes(
+                            n, ct.S_w * ct.Y, ct.S, ct.n_samples), dtype=torch.uint8, device=dev)
+                    _ffi.check(self._lib.w2a_rollout_mfma_prepare(self._h, self._mfma_ws.data_ptr(), self._mfma_ws.numel(),
+                                                                  self._stream()), "w2a_rollout_mfma_prepare")
             if self._pm:
                 steps = self._rollout_posterior_mean(p, steps, out, mask, amask, words, snap, st0)
             else:
