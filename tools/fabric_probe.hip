@@ -21,6 +21,11 @@ struct u3 { uint32_t a, b, c; };
 #define U3_A(v) (v).a
 #endif
 
+#ifdef PROBE_ZSTREAM  // what-if: no coefficient-row gather; the baseline logit's table part streams in as 4 B per env from a
+                      // per-episode [day][env] array and the four run-time coefficients as 16 B per env
+__device__ const float *g_Z;
+__device__ const float4 *g_Wrt;
+#endif
 template <bool STREAM, bool GATHER>
 __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc, const int32_t *act, u3 *hot_out,
                                                   float *reward, uint8_t *done, float *obs, const float4 *W,
@@ -43,6 +48,13 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   u3 h = {}, c = {};
   int32_t a = 0;
   if (STREAM) { h = hot[e]; c = stepc[e]; a = act[e]; }
+#ifdef PROBE_ZSTREAM
+  if (STREAM) {
+    const float zz = g_Z[(size_t)(n_raw >> 40) * (size_t)n + e];
+    const float4 wr = g_Wrt[e];
+    acc = zz + wr.x * 0.5f + wr.y * 0.25f + wr.z * 0.125f + wr.w;
+  }
+#endif
   const int p = lane & 7, g = lane >> 3;
 #ifdef PROBE_DEP  // like k_step64: the gather indices are part of the streamed state (lane = env) and reach the
                   // 8-lanes-per-row mapping through LDS, so the gathers wait for the state loads
@@ -70,7 +82,11 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
 #ifdef PROBE_DEP
         const uint2 dd = desc[wave][pass * 32 + r * 8 + g];
         x[r] = X[dd.x * 8 + p];
+#ifdef PROBE_ZSTREAM
+        w[r] = x[r];
+#else
         w[r] = W[dd.y * 16 + p];
+#endif
 #else
         x[r] = X[xrow[j] * 8 + p];  // xrow / wrow are read as 8-lane broadcasts (the real kernel takes them from LDS)
         w[r] = W[wrow[j] * 16 + p];
@@ -144,6 +160,14 @@ int main() {
     for (size_t i = 0; i < nw; ++i) { q ^= q << 13; q ^= q >> 7; q ^= q << 17; hb[i] = (float)((q >> 40) * (1.0 / 16777216.0)) - 0.5f; }
     CHECK(hipMemcpy(W, hb, nw * 4, hipMemcpyHostToDevice));
     free(hb);
+  }
+#endif
+#ifdef PROBE_ZSTREAM
+  {
+    float *Z; float4 *Wrt;
+    CHECK(hipMalloc(&Z, (size_t)153 * n * 4)); CHECK(hipMalloc(&Wrt, n * 16));
+    CHECK(hipMemset(Z, 0x3c, (size_t)153 * n * 4)); CHECK(hipMemset(Wrt, 0x3c, n * 16));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_Z), &Z, sizeof(Z))); CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_Wrt), &Wrt, sizeof(Wrt)));
   }
 #endif
   uint32_t *hw = (uint32_t *)malloc(n * 4), *hx = (uint32_t *)malloc(n * 4);

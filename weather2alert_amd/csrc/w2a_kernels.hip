@@ -103,6 +103,21 @@ static void launch_rollout(int kind, bool masks, bool fixes, unsigned grid, hipS
   }
 }
 
+template <int KIND>
+static void launch_rollout_mfma_kind(bool masks, unsigned grid, hipStream_t s, const RmArgs &ra) {
+  if (masks) hipLaunchKernelGGL((k_rollout_mfma<KIND, true>), dim3(grid), dim3(64 * RM_WAVES), 0, s, ra);
+  else hipLaunchKernelGGL((k_rollout_mfma<KIND, false>), dim3(grid), dim3(64 * RM_WAVES), 0, s, ra);
+}
+static void launch_rollout_mfma(int kind, bool masks, unsigned grid, hipStream_t s, const RmArgs &ra) {
+  switch (kind) {
+    case W2A_POLICY_ALWAYS: launch_rollout_mfma_kind<W2A_POLICY_ALWAYS>(masks, grid, s, ra); break;
+    case W2A_POLICY_BERNOULLI: launch_rollout_mfma_kind<W2A_POLICY_BERNOULLI>(masks, grid, s, ra); break;
+    case W2A_POLICY_THRESHOLD: launch_rollout_mfma_kind<W2A_POLICY_THRESHOLD>(masks, grid, s, ra); break;
+    case W2A_POLICY_TABLE: launch_rollout_mfma_kind<W2A_POLICY_TABLE>(masks, grid, s, ra); break;
+    default: launch_rollout_mfma_kind<W2A_POLICY_NEVER>(masks, grid, s, ra); break;
+  }
+}
+
 extern "C" {
 
 int w2a_abi_version(void) { return W2A_ABI_VERSION; }
@@ -638,7 +653,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.wscale = env->rm_wscale;
     ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs;
     const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
-    hipLaunchKernelGGL(k_rollout_mfma, dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * RM_WAVES), 0, s, ra);
+    launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());
     return W2A_OK;
   }
@@ -757,6 +772,7 @@ int w2a_invalidate(w2a_env *env) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
   if (env->budget_bound != INT64_MAX) env->budget_bound_known = env->budget_bound;
   env->pk_valid = 0; env->canon_valid = 1; env->uni_t = -1; env->perm_valid = 0; env->budget_bound = INT64_MAX;
+  env->rm_valid = 0;  // feature rows may have changed behind the handle: the matrix-core rollout's tile list is stale
   return W2A_OK;
 }
 

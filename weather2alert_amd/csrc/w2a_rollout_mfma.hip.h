@@ -79,6 +79,10 @@ __global__ void k_rm_bounds(const uint32_t *cursor, int32_t rows, uint32_t *star
   end[r] = cursor[r];
 }
 
+// Compiled per policy kind and with / without the day bitmaps + return snapshot (like k_rollout64): with two waves per
+// SIMD resident the day loop is bound by the latency of its own instruction chain, and those wave-uniform choices
+// otherwise cost a dozen scalar branches per day.
+template <int KIND, bool MASKS>
 __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs ra) {
   const RolloutArgs &a = ra.r;
   __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
   }
   const float *Xf = reinterpret_cast<const float *>(a.tb.X);
   const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
-  const int32_t kind = a.pol.kind;
+  constexpr int32_t kind = KIND;
   float ret = 0.0f;
   int32_t alerts = 0, over = 0;
   uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
         ret_total += r;
         alerts += (int32_t)actual;
         over += (act == 1 && atb_s) ? 1 : 0;
-        if (a.alert_mask && actual) {
+        if (MASKS && a.alert_mask && actual) {
           const uint32_t wi = t >> 5;
           if (wi != mask_idx) {
             if (mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
           }
           mask_word |= 1u << (t & 31);
         }
-        if (a.attempt_mask && act == 1) {
+        if (MASKS && a.attempt_mask && act == 1) {
           const uint32_t wi = t >> 5;
           if (wi != att_idx) {
             if (att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
           }
           att_word |= 1u << (t & 31);
         }
-        if ((done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
+        if (MASKS && (done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
         used = used2; hist = hist2; last = actual; atb = atb_s;
         if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
         else { fin = true; active = false; }
@@ -285,11 +289,11 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
     if (a.ret_out) a.ret_out[e] = ret;
     if (a.alerts_out) a.alerts_out[e] = alerts;
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
-    if (a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
+    if (MASKS && a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
       a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
-    if (a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
+    if (MASKS && a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
       a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
-    if (a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
+    if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
   }
 }

@@ -391,4 +391,6 @@ class DeviceTables:
         bits = np.packbits(g.reshape(ct.T, gw, 32), axis=2, bitorder="little").view(np.uint32).reshape(ct.T, gw)
         self.gate_bits = t(bits)
         s.gate_bits, s.gate_words = self.gate_bits.data_ptr(), gw
+        if os.environ.get("W2A_NO_GATE_BITS"):  # A/B: every alerting env fetches its effectiveness row (no bitmap lookup)
+            s.gate_bits, s.gate_words = None, 0
         self.struct = s
