@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 13
+#define W2A_ABI_VERSION 14
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -306,7 +306,9 @@ int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
 /* What the handle knows (host-side bookkeeping, no device work): the day every env is on if the batch is known to be in
  * lock step (-1 otherwise); whether tables and budgets allow the lock-step mirror at all; which of the two forms of
  * the step state is current. */
-enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3 };
+enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3,
+       W2A_Q_LAST_ROLLOUT_KERNEL = 4 /* what the last w2a_rollout launched: -1 none yet, 0 k_rollout (4 lanes per env),
+                                        1 k_rollout64 (lane = env), 2 k_rollout_mfma (int8 matrix cores) */ };
 int w2a_query(w2a_env *env, int what);
 
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived

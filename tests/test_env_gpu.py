@@ -772,6 +772,7 @@ def test_matrix_core_rollout_matches_vector_rollout_and_oracle(dev, kind):
         return oa
 
     check(21)   # starts on day 0, ends inside a 16-day chunk
+    assert A.last_rollout_kernel == "k_rollout_mfma" and B.last_rollout_kernel == "k_rollout64"
     check(16)   # a whole chunk starting on day 21
     for _ in range(3):  # explicit steps: the handle keeps track of the day
         a = (rng.random(n) < 0.2).astype(np.int32)

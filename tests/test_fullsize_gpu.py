@@ -183,10 +183,12 @@ class _Draw:
         return O.devrng_policy_uniform(self.seed, int(self.gids[i]), int(self.ep[i]), t)
 
 
-@pytest.mark.parametrize("kind", ["threshold", "bernoulli"])
-def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
+@pytest.mark.parametrize("kind,kernel", [("threshold", "k_rollout_mfma"), ("bernoulli", "k_rollout_mfma"),
+                                         ("threshold", "k_rollout64"), ("bernoulli", "k_rollout64")])
+def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind, kernel):
     """rollout() at BASELINE configs[2] size (1 048 576 envs, S = 746, 100 draws, similar_climate_counties) through
-    k_rollout64 + the counting-sort visiting order (w2a_rollout_order), whole episode in one launch, against the
+    the counting-sort visiting order (w2a_rollout_order) and either the matrix-core kernel (k_rollout_mfma: feature-row
+    tile list, int8 MFMAs for the table part of the logits) or k_rollout64, whole episode in one launch, against the
     oracle's policy loop on ~8 192 sampled envs (incl. env 0 and the last one): alerts, over-budget attempts, alert-day
     and attempt-day bitmaps exact, returns <= 2e-5 relative; every env finished; the order is a permutation."""
     from weather2alert_amd import HeatAlertVecEnv
@@ -195,7 +197,7 @@ def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
     V.reward_mode = "sampled"
     n, gid0 = 1 << 20, 12345
     env = HeatAlertVecEnv(n, tables=dt, device=dev, similar_climate_counties=True, autoreset="disabled", env_gid0=gid0,
-                          rollout_order=True)
+                          rollout_order=True, rollout_mfma=kernel == "k_rollout_mfma")
     env.reset(seed=31)
     idx = _sample(n, 8192)
     it = torch.as_tensor(idx, device=dev)
@@ -210,7 +212,8 @@ def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
         draw = _Draw(99, gid0 + idx, st["episode_no"])
         np.testing.assert_array_equal(draw.vec(np.full(len(idx), 3))[:5], [draw(i, 3) for i in range(5)])
     out = env.rollout(pol, alert_mask=True)
-    assert env._order_ws is not None and not env._order_stale  # the lane = env kernel ran on the visiting order
+    assert env._order_ws is not None and not env._order_stale  # the kernel ran on the visiting order
+    assert env.last_rollout_kernel == kernel
     order = env._order_ws[: 4 * n].view(torch.int32)
     assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device=dev))  # a permutation of the env ids
     ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, dict(pol, col=ct.columns.index("heat_qi")), ct.T, draw)
@@ -231,7 +234,7 @@ def test_full_size_rollout_with_visiting_order_vs_oracle(dev, kind):
     assert bool((sa["used"] <= sa["budget"]).all()) and bool((out["alerts"] == sa["used"]).all())
     assert bool(((out["attempts_over_budget"] == 0) | (sa["used"] == sa["budget"])).all())
     assert env.check_status() == 0
-    print(f"full-size rollout [{kind}]: sample {len(idx)} envs, max rel |return - oracle| = {rel:.3e}")
+    print(f"full-size rollout [{kind}, {kernel}]: sample {len(idx)} envs, max rel |return - oracle| = {rel:.3e}")
     env.close()
 
 

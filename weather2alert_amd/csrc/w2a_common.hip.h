@@ -191,6 +191,7 @@ struct w2a_env {
   const uint32_t *rm_rowflag;
   const float *rm_xs;
   int rm_valid;                  // the tile list belongs to the current episode's visiting order
+  int last_rollout_kernel;       // W2A_Q_LAST_ROLLOUT_KERNEL
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
   // which form of the per-env step state is current (see StateArrays): the canonical arrays, the lock-step mirror,

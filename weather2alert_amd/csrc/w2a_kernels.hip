@@ -225,7 +225,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->perm_valid = 0;
   h->pm_kernel = W2A_PM_VECTOR;
   h->xmax_ws = nullptr;
-  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0;
+  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0; h->last_rollout_kernel = -1;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -655,8 +655,10 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());
+    env->last_rollout_kernel = 2;
     return W2A_OK;
   }
+  env->last_rollout_kernel = (W2A_ROLLOUT_WIDE && a.order) ? 1 : 0;
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
@@ -764,6 +766,7 @@ int w2a_query(w2a_env *env, int what) {
     case W2A_Q_PACKED_ELIGIBLE: return (env->pk_static_ok && env->budget_bound <= 65535 && env->uni_nd > 0) ? 1 : 0;
     case W2A_Q_PACKED_CURRENT: return env->pk_valid;
     case W2A_Q_CANONICAL_CURRENT: return env->canon_valid;
+    case W2A_Q_LAST_ROLLOUT_KERNEL: return env->last_rollout_kernel;
     default: return fail(W2A_ERR_ARG, "w2a_query: unknown item");
   }
 }

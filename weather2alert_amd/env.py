@@ -317,6 +317,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
         return bool(self._lib.w2a_query(self._h, _ffi.Q_PACKED_CURRENT)) and not bool(
             self._lib.w2a_query(self._h, _ffi.Q_CANONICAL_CURRENT))
 
+    @property
+    def last_rollout_kernel(self) -> str | None:
+        """Which kernel the last sampled-reward rollout() launched: "k_rollout_mfma" (int8 matrix cores), "k_rollout64"
+        (lane = env, vector ALU), "k_rollout" (4 lanes per env) or None before the first one."""
+        return {0: "k_rollout", 1: "k_rollout64", 2: "k_rollout_mfma"}.get(
+            self._lib.w2a_query(self._h, _ffi.Q_LAST_ROLLOUT_KERNEL))
+
     def _stream(self):
         if self._raw_stream is not None:
             return self._raw_stream(self._dev_index)
