@@ -26,6 +26,15 @@ struct u3 { uint32_t a, b, c; };
 __device__ const float *g_Z;
 __device__ const float4 *g_Wrt;
 #endif
+#ifdef PROBE_ONEPASS  // what-if: all 64 envs of the wave gathered in ONE pass of 8 rounds (two memory hops per wave
+                      // instead of three, twice the gathered bytes in flight), one 64-env observation flush
+#define P_PASSES 1
+#define P_ROUNDS 8
+#else
+#define P_PASSES 2
+#define P_ROUNDS 4
+#endif
+#define P_PASS_ENVS (P_ROUNDS * 8)
 template <bool STREAM, bool GATHER>
 __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc, const int32_t *act, u3 *hot_out,
                                                   float *reward, uint8_t *done, float *obs, const float4 *W,
@@ -35,7 +44,7 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   X += (size_t)(n >> 40) * 8206 * 8;  // day slice in the upper bits of n (keeps the signature)
   n &= (1ll << 40) - 1;
 #endif
-  __shared__ float tile[4][32 * 32];
+  __shared__ float tile[4][P_PASS_ENVS * 32];
 #ifdef PROBE_LDS_PAD   // caps the occupancy like k_step64's register count does (-DPROBE_LDS_PAD=bytes)
   __shared__ float pad[PROBE_LDS_PAD / 4];
   if (n < 0) pad[threadIdx.x] = 0.f;
@@ -64,10 +73,11 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
-  for (int pass = 0; pass < 2; ++pass) {
-    float4 x[4], w[4];
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t j = (uint32_t)env0 + pass * 32 + r * 8 + g;
+  for (int pass = 0; pass < P_PASSES; ++pass) {
+    float4 x[P_ROUNDS], w[P_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < P_ROUNDS; ++r) {
+      const uint32_t j = (uint32_t)env0 + pass * P_PASS_ENVS + r * 8 + g;
       x[r] = make_float4(1.f, 2.f, 3.f, 4.f);
 #ifdef PROBE_RANDOM_DATA  // stream-only mode too writes values that do not repeat
       {
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
       w[r] = x[r];
       if (GATHER) {
 #ifdef PROBE_DEP
-        const uint2 dd = desc[wave][pass * 32 + r * 8 + g];
+        const uint2 dd = desc[wave][pass * P_PASS_ENVS + r * 8 + g];
         x[r] = X[dd.x * 8 + p];
 #ifdef PROBE_ZSTREAM
         w[r] = x[r];
@@ -93,7 +103,8 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
 #endif
       }
     }
-    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int r = 0; r < P_ROUNDS; ++r) {
 #ifdef PROBE_F64  // the step kernel's arithmetic: two 4-term fp64 chains and an 8-lane fp64 all-reduce per env
       {
         double zb = (double)x[r].x * (double)w[r].x, ze = (double)x[r].x * (double)w[r].y;
@@ -116,10 +127,10 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
     }
     if (STREAM) {
       __builtin_amdgcn_wave_barrier();
-      float *dst = obs + (env0 + pass * 32) * 29;
-      for (int c0 = 0; c0 < 256; c0 += 64) {
+      float *dst = obs + (env0 + pass * P_PASS_ENVS) * 29;
+      for (int c0 = 0; c0 < P_PASS_ENVS * 8; c0 += 64) {
         const int ch = c0 + lane;
-        if (ch < 232) __builtin_nontemporal_store(reinterpret_cast<const v4f *>(tile[wave])[ch], reinterpret_cast<v4f *>(dst) + ch);
+        if (ch < P_PASS_ENVS * 29 / 4) __builtin_nontemporal_store(reinterpret_cast<const v4f *>(tile[wave])[ch], reinterpret_cast<v4f *>(dst) + ch);
       }
       __builtin_amdgcn_wave_barrier();
     }

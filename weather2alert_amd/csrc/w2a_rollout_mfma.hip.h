@@ -22,7 +22,10 @@
 // group) conversions -> the chunk's feature digits in the wave's LDS; 4 row tiles x 2 heads x 6 MFMAs; the int32 sums ->
 // f32 logit parts -> LDS [env][day][head]; then 16 days of k_rollout64's day loop with 3 + 3 fp64 FMAs in place of
 // 30 + 30. Outputs, RNG streams and state are those of k_rollout64 (indexed by env id).
-#define RM_WAVES 4
+#ifndef RM_WAVES
+#define RM_WAVES 1  // waves (= tiles) per workgroup: no workgroup-level synchronisation is used, and single-wave workgroups
+                    // leave the dispatcher the finest grain (measured 0.87 / 0.88 / 0.90 ms per episode for 1 / 2 / 4)
+#endif
 #define RM_ZSTRIDE 33  // floats per env of the logit-part image: 16 days x 2 heads + 1 pad (lane = env reads, bank-conflict free)
 
 struct RmArgs {
@@ -82,8 +85,11 @@ __global__ void k_rm_bounds(const uint32_t *cursor, int32_t rows, uint32_t *star
 // Compiled per policy kind and with / without the day bitmaps + return snapshot (like k_rollout64): with two waves per
 // SIMD resident the day loop is bound by the latency of its own instruction chain, and those wave-uniform choices
 // otherwise cost a dozen scalar branches per day.
+#ifndef RM_MIN_WAVES
+#define RM_MIN_WAVES 3  // waves per SIMD the kernel is compiled for (168 VGPRs; 2: 0.99 ms, 4: 1.04 ms with spills)
+#endif
 template <int KIND, bool MASKS>
-__global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs ra) {
+__global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(const RmArgs ra) {
   const RolloutArgs &a = ra.r;
   __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
   __shared__ float sZ[RM_WAVES][64][RM_ZSTRIDE];                                      // logit parts [env][day * 2 + head]
@@ -92,8 +98,13 @@ __global__ __launch_bounds__(64 * RM_WAVES, 3) void k_rollout_mfma(const RmArgs 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
+  // The grid is sized for the worst case (n / 64 + feature rows tiles); the tiles there are get an eighth per XCD, dealt
+  // from the actual count -- with the grid's eighths the surplus workgroups would all fall on the last XCDs and leave
+  // them idle (at 1 M envs / 8 206 rows: 20.5 K tiles of 24.6 K, XCD 7 empty and XCD 6 a third full: 1.03 -> 0.90 ms)
   const uint32_t n_tiles = *ra.n_tiles;
-  const uint32_t tile = logical_block(blockIdx.x, gridDim.x >> 3) * RM_WAVES + wave;
+  const uint32_t n_wgs = (n_tiles + RM_WAVES - 1) / RM_WAVES, per_xcd = (n_wgs + 7u) >> 3;
+  if ((blockIdx.x >> 3) >= per_xcd) return;
+  const uint32_t tile = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * RM_WAVES + wave;
   if (tile >= n_tiles) return;  // whole wave; only wave-level synchronisation below
   const uint4 tl = ra.tiles[tile];
   const int count = (int)__builtin_amdgcn_readfirstlane(tl.y);
