@@ -23,7 +23,8 @@
 //   * workgroup -> env-tile mapping is XCD-aware (logical_block); k_step64 (w2a_step64.hip.h) is the lean
 //     64-envs-per-wave form of the same step for plain lock-step batches; the posterior-mean reward contraction
 //     (w2a_posterior.hip.h) exists as a vector-ALU kernel (default) and as matrix-unit (MFMA) kernels, selected at
-//     run time by w2a_set_posterior_kernel -- the only MFMA users of the library.
+//     run time by w2a_set_posterior_kernel; the matrix unit's other user is the policy rollout k_rollout_mfma
+//     (w2a_rollout_mfma.hip.h: the table-sourced part of both logits per (county, year) tile as int8 MFMAs).
 //
 // No fallback path exists: without this library (or without a ROCm device) constructing an env raises.
 
