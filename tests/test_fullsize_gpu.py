@@ -170,6 +170,49 @@ def _sample(n, k):
     return np.unique(np.concatenate([np.arange(0, n, max(n // k, 1)), [n - 1]]))
 
 
+def test_eight_million_envs_on_one_gpu(dev):
+    """BASELINE configs[4]'s TOTAL batch (8 388 608 envs) + a ragged tail of 13 on one GPU: observation offsets pass
+    2^31 bytes (973 MB of rows), the last wave is partial. 20 days of step() and a whole-episode rollout on the
+    matrix-core kernel against the oracle on a strided sample that includes env 0 and the LAST env."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("nn_full_medicare_all", dev)
+    V.reward_mode = "sampled"
+    n = 8388608 + 13
+    env = HeatAlertVecEnv(n, tables=dt, device=dev, autoreset="disabled")
+    obs, _ = env.reset(seed=77)
+    idx = _sample(n, 4096)
+    assert idx[-1] == n - 1
+    it = torch.as_tensor(idx, device=dev)
+    st = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+    obs_o = V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+    g = torch.Generator(device=dev).manual_seed(9)
+    worst = 0.0
+    for t in range(20):
+        a = (torch.rand(n, device=dev, generator=g) < 0.15).to(torch.uint8)
+        obs, r, done, _, _ = env.step(a)
+        obs_o, r_o, done_o, _ = V.step(a[it].cpu().numpy().astype(np.int32))
+        worst = max(worst, float(np.abs(r[it].cpu().numpy().astype(np.float64) - r_o).max()))
+        np.testing.assert_array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32))
+    assert worst <= REWARD_TOL and env.step_kernel_name == "k_step64" and env.packed_state
+    # the rest of the episode in one launch (lock step known to the handle: the matrix-core kernel serves it)
+    V._finished = np.zeros(len(idx), bool)
+    pol = dict(kind="threshold", feature="heat_qi", threshold=0.85, require_budget=True)
+    out = env.rollout(pol, alert_mask=True)
+    assert env.last_rollout_kernel == "k_rollout_mfma"
+    ret_o, al_o, ov_o, days_o = O.oracle_rollout(V, dict(pol, col=ct.columns.index("heat_qi")), ct.T, None)
+    np.testing.assert_array_equal(out["alerts"][it].cpu().numpy(), al_o)
+    np.testing.assert_array_equal(out["alert_days"][it].cpu().numpy(), days_o)
+    np.testing.assert_allclose(out["return"][it].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-4)
+    sa = env.state()
+    assert bool(out["done"].all()) and bool((sa["used"] <= sa["budget"]).all()) and env.check_status() == 0
+    print(f"8 388 621 envs: sample {len(idx)} envs, max |reward - oracle| = {worst:.3e}")
+    env.close()
+    del env, obs, out, sa
+    torch.cuda.empty_cache()
+
+
 class _Draw:
     """Bernoulli-policy uniforms of the sampled envs (the build's counter RNG, restated in the oracle)."""
 
