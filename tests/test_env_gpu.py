@@ -1581,3 +1581,23 @@ def test_rccl_single_rank_return_gather(dev):
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_randomised_parity_sweep(dev):
+    """tools/stress_parity.py, 16 seeded cases: random table shapes (S, Y, T, draws), batch sizes around the tile
+    boundaries (1, 63, 64, 65, 255 ... 4097), budgets, action rates and policies through every step-kernel form, both
+    sampled-reward rollout kernels and the posterior-mean kernels, each against the oracle (the 640-case run is
+    profiles/r03/stress_parity.log)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                               "stress_parity.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    rng = np.random.default_rng(2024)
+    kernels = set()
+    for i in range(16):
+        w, wp, k = sp.run_case(i, rng, dev)
+        assert w <= REWARD_TOL and wp <= REWARD_TOL
+        kernels.add(k)
+    assert "k_rollout_mfma" in kernels
