@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
         x[r] = X[dd.x * 8 + p];
 #ifdef PROBE_ZSTREAM
         w[r] = x[r];
+#elif defined(PROBE_WDENSE)  // what-if: baseline coefficient rows on consecutive 128-B lines ([head][row][32] instead of
+                             // [row][head][32], where they sit on every other line: half the L2 channels / sets)
+        w[r] = W[dd.y * 8 + p];
 #else
         w[r] = W[dd.y * 16 + p];
 #endif
