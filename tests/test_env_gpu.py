@@ -266,6 +266,48 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     old.close()
 
 
+@pytest.mark.parametrize("n,write_obs,augment", [(257, True, False), (4096 + 5, True, True), (1000, False, False), (63, True, True)])
+def test_step64_in_kernel_autoreset_equals_classic_kernel(dev, n, write_obs, augment):
+    """Batches that are not in lock step (ragged episode lengths here; masked resets elsewhere) restart finished envs
+    inside the step kernel. The 64-envs-per-wave kernel's rare per-lane epilogue (k_step64<..., AUTORESET>) against the
+    4-lanes-per-env kernel's (k_step<AUTORESET>): 340 steps, every env crosses two or three episode boundaries at its
+    own time -- observations (incl. the first row of every new episode), done flags, final returns, episode tuples and
+    episode numbers identical, rewards to the order of the fp64 additions; sticky sampled budgets carried over."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=20, years=[2006, 2007, 2008], n_samples=9, seed=43, extra_confounder_fips=3)
+    rng = np.random.default_rng(n)
+    sd.meta["n_days_per_episode"] = rng.integers(120, 154, size=(20, 3))
+    ct = tables.compile_from_synth(sd)
+    kw = dict(tables=ct, device=dev, write_obs=write_obs, similar_climate_counties=augment, env_gid0=77, lockstep=False)
+    new, old = HeatAlertVecEnv(n, step_kernel="wide", **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
+    assert new.step_kernel_name == "k_step64" and old.step_kernel_name == "k_step" and new._dev_auto and old._dev_auto
+    opts = {"sample_budget": True, "sample_budget_type": "centered"}
+    o1, _ = new.reset(seed=5, options=opts)
+    o2, _ = old.reset(seed=5, options=opts)
+    assert torch.equal(o1, o2)
+    n_done = 0
+    for t in range(340):
+        a = torch.as_tensor((rng.random(n) < 0.25).astype(np.int32), device=dev)
+        o1, r1, d1, _, i1 = new.step(a)
+        o2, r2, d2, _, i2 = old.step(a)
+        assert torch.equal(d1, d2) and torch.equal(o1, o2), t
+        assert torch.allclose(r1, r2, rtol=0, atol=1e-6), t
+        n_done += int(d1.sum())
+        if t % 60 == 59:
+            s1, s2 = new.state(), old.state()
+            for k in s1:
+                if k == "episode_return":
+                    assert torch.allclose(s1[k], s2[k], rtol=1e-5, atol=1e-5), k
+                else:
+                    assert torch.equal(s1[k], s2[k]), (k, t)
+            assert torch.allclose(new._final_return, old._final_return, rtol=1e-5)
+    assert n_done >= 2 * n and int(new.state()["episode_no"].min()) >= 2  # every env restarted at least twice
+    assert new.check_status() == old.check_status() == 0
+    new.close()
+    old.close()
+
+
 def test_packed_lockstep_state_equals_canonical_state(dev):
     """While a batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env state
     (day / episode length / finished bit as kernel arguments) instead of the 24-B canonical words. Same arithmetic, so

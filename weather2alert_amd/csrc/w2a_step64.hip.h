@@ -97,7 +97,10 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 // One 64-env tile of one wave, phases A..C, from the tile's already loaded state words and action.
 // REWARD_GIVEN: a.reward already holds today's reward (w2a_posterior_mean_reward ran on the same state and actions):
 // no coefficient gather and no logits here, the rest of env.py:238-262 as usual.
-template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED>
+// AUTORESET: same-step autoreset for batches that are not in lock step (masked resets, ragged episode lengths): an env
+// whose terminal step has just run draws its next episode and gets that episode's first observation, as in
+// k_step<AUTORESET> -- here as a rare per-lane epilogue (one env-day in n_days), on the canonical state words.
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED, bool AUTORESET = false>
 __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const int lane, const int64_t wave_env0,
                                          const bool valid, const uint32_t e, const u3 h, const u3 c, const int32_t act,
                                          const int4 so) {
@@ -277,6 +280,35 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   if (done && a.last_return) a.last_return[e] = ret;
   if (st_bits) atomicOr(a.status, (int)st_bits);
   }
+  if (AUTORESET) {
+    // env.py:162-181 for the envs that finished today: next episode from the device RNG (draw_episode, the k_reset /
+    // k_step<AUTORESET> code), its state words over the ones phase C has just written, its day-0 row as the returned
+    // observation (the pass flush left the finished env's row alone)
+    const bool rs = valid && done;
+    if (__any(rs)) {
+      if (rs) {
+        const uint4 cold = load_cold(a.st, e);
+        const Episode ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
+        if (ep.bad) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
+        store_episode(a.st, e, make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1),
+                      make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
+        if (WRITE_OBS) {
+          float *row = reinterpret_cast<float *>(a.obs) + (size_t)e * n_obs;
+          const float4 *xr = a.tb.X + (size_t)ep.ep_row * (ROWF / 4);  // day 0
+#pragma unroll
+          for (int qd = 0; qd < ROWF / 4; ++qd) {
+            float4 v = xr[qd];
+            if (qd == RT_QUAD) v = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+            const int4 sq = reinterpret_cast<const int4 *>(a.slot_obs)[qd];
+            if (sq.x >= 0) row[sq.x] = v.x;
+            if (sq.y >= 0) row[sq.y] = v.y;
+            if (sq.z >= 0) row[sq.z] = v.z;
+            if (sq.w >= 0) row[sq.w] = v.w;
+          }
+        }
+      }
+    }
+  }
 }
 
 // packed variant: 8 + 8 B per env, the uniform day / episode length from the kernel arguments; the canonical words are
@@ -312,7 +344,7 @@ __device__ __forceinline__ void s64_load_state(const StepArgs &a, uint32_t e, u3
 // action streams, 28 B per env) has few bytes in flight and a full memory round trip of latency; requesting the
 // NEXT tile's words before the current tile's phases run takes that hop off the wave's critical path for every
 // tile but the first (7 more VGPRs). Measured: DESIGN.md §4.
-template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED = false>
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED = false, bool AUTORESET = false>
 __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
   const int tid = threadIdx.x;
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       if (PACKED) s64_load_packed(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
       else s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
     }
-    s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED>(a, sw, lane, env0, valid, e, h, c, act, so);
+    s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED, AUTORESET>(a, sw, lane, env0, valid, e, h, c, act, so);
     // the per-wave LDS record is rewritten by the next tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -55,14 +55,14 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
-  if (wide && !autoreset && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
+  if (wide && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
     const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
     const int64_t tiles = (env->n + per_wg - 1) / per_wg;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
     // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
-    const bool packed = !given && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
+    const bool packed = !given && !autoreset && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
                         env->budget_bound <= 65535 && !env->graph_captured;
     if (packed) {
       if (!env->pk_valid) {  // entering the packed form (once per episode): the canonical arrays are current
@@ -84,6 +84,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     if (given) {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
+    } else if (autoreset) {  // batches that left lock step: the finished envs restart inside the kernel (rare epilogue)
+      if (no_obs) hipLaunchKernelGGL((k_step64<false, false, false, true>), grid64, block, 0, s, a);
+      else hipLaunchKernelGGL((k_step64<true, false, false, true>), grid64, block, 0, s, a);
     } else {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, false>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
