@@ -21,7 +21,7 @@
 //   * the effectiveness coefficient row is fetched only for envs that issue an alert today
 //     (it enters the reward through eff * actual, env.py:221): half the gather traffic;
 //   * workgroup -> env-tile mapping is XCD-aware (logical_block); k_step64 (w2a_step64.hip.h) is the lean
-//     64-envs-per-wave form of the same step for plain lock-step batches; the posterior-mean reward contraction
+//     64-envs-per-wave form of the same step for large batches with faithful semantics; the posterior-mean reward contraction
 //     (w2a_posterior.hip.h) exists as a vector-ALU kernel (default) and as matrix-unit (MFMA) kernels, selected at
 //     run time by w2a_set_posterior_kernel; the matrix unit's other user is the policy rollout k_rollout_mfma
 //     (w2a_rollout_mfma.hip.h: the table-sourced part of both logits per (county, year) tile as int8 MFMAs).

@@ -1,5 +1,5 @@
-// w2a_step64.hip.h -- k_step64: one day for every env (env.py:238-262), the lean form of k_step for batches that
-// need neither the in-kernel autoreset nor the corrected-semantics flags (w2a_step picks it from 131 072 envs up).
+// w2a_step64.hip.h -- k_step64: one day for every env (env.py:238-262), the lean form of k_step for batches with
+// faithful semantics (w2a_step picks it from 131 072 envs up; the in-kernel autoreset is a rare per-lane epilogue).
 // Part of libw2a.so; included only by w2a_kernels.hip (one translation unit, see the file comment there).
 #ifndef W2A_STEP64_HIP_H
 #define W2A_STEP64_HIP_H

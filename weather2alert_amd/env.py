@@ -88,9 +88,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why). The kernels
                          agree to ~1e-7, not to the last bit: name one for run-to-run bit reproducibility (a
                          checkpoint carries the choice, so a resumed run continues on the same kernel).
-    step_kernel          "auto" (default): plain lock-step / autoreset-disabled batches of >= 131 072 envs run the
-                         64-envs-per-wave kernel (csrc/w2a_step64.hip.h), everything else the 4-lanes-per-env kernel
-                         (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
+    step_kernel          "auto" (default): batches of >= 131 072 envs with faithful semantics run the 64-envs-per-wave
+                         kernel (csrc/w2a_step64.hip.h; in-kernel autoreset included), everything else the
+                         4-lanes-per-env kernel (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
                          results up to the order of the fp64 additions; for A/B measurements and tests). While the
                          batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env
                          state instead of the 24-B canonical words (include/w2a.h, w2a_state_bytes; identical
