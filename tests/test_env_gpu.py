@@ -239,6 +239,7 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     kw = dict(tables=ct, device=dev, autoreset="disabled", write_obs=write_obs)
     new, old = HeatAlertVecEnv(n, step_kernel="wide", **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
     assert new.step_kernel_name == "k_step64" and old.step_kernel_name == "k_step"
+    assert new.metadata["autoreset_mode"] == "disabled" and type(new).metadata["autoreset_mode"] == "same_step"
     o1, _ = new.reset(options={"episodes": ep})
     o2, _ = old.reset(options={"episodes": ep})
     assert torch.equal(o1, o2)

@@ -91,12 +91,20 @@ def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monke
     import sys
     import types
 
+    import enum
+
     class FakeVectorEnv:
         metadata: dict = {}
+
+    class FakeAutoresetMode(enum.Enum):
+        NEXT_STEP = "NextStep"
+        SAME_STEP = "SameStep"
+        DISABLED = "Disabled"
 
     gym = types.ModuleType("gymnasium")
     vec = types.ModuleType("gymnasium.vector")
     vec.VectorEnv = FakeVectorEnv
+    vec.AutoresetMode = FakeAutoresetMode
     gym.vector = vec
     monkeypatch.setitem(sys.modules, "gymnasium", gym)
     monkeypatch.setitem(sys.modules, "gymnasium.vector", vec)
@@ -106,7 +114,8 @@ def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monke
         m = importlib.reload(envmod)
         assert issubclass(m.HeatAlertVecEnv, FakeVectorEnv)
         cls = m.HeatAlertVecEnv
-        assert cls.metadata["autoreset_mode"] == "same_step" and cls.spec is None and cls.render_mode is None
+        assert cls.metadata["autoreset_mode"] is FakeAutoresetMode.SAME_STEP and cls.spec is None and cls.render_mode is None
+        assert m._autoreset_metadata("disabled") is FakeAutoresetMode.DISABLED
         for attr in ("np_random", "np_random_seed", "unwrapped"):
             assert isinstance(getattr(cls, attr), property)
         for meth in ("reset", "step", "close"):
@@ -116,3 +125,4 @@ def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monke
         monkeypatch.delitem(sys.modules, "gymnasium.vector")
         importlib.reload(envmod)
     assert envmod.HeatAlertVecEnv.__mro__[1] is object
+    assert envmod.HeatAlertVecEnv.metadata["autoreset_mode"] == "same_step" and envmod._autoreset_metadata("disabled") == "disabled"

@@ -32,6 +32,17 @@ try:  # a real Gymnasium VectorEnv when the package is importable; the same duck
     from gymnasium.vector import VectorEnv as _VectorEnvBase
 except ImportError:  # gymnasium is not a dependency of the reference's numerical path
     _VectorEnvBase = object
+try:  # gymnasium >= 1.0 names the autoreset behaviour of a vector env with this enum (metadata["autoreset_mode"])
+    from gymnasium.vector import AutoresetMode as _AutoresetMode
+except ImportError:
+    _AutoresetMode = None
+
+
+def _autoreset_metadata(mode: str):
+    """metadata["autoreset_mode"]: gymnasium's AutoresetMode member when the package has one, else the plain string."""
+    if _AutoresetMode is None:
+        return mode
+    return {"same_step": _AutoresetMode.SAME_STEP, "disabled": _AutoresetMode.DISABLED}[mode]
 
 
 class HeatAlertVecEnv(_VectorEnvBase):
@@ -99,7 +110,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
 
-    metadata = {"autoreset_mode": "same_step"}
+    metadata = {"autoreset_mode": _autoreset_metadata("same_step")}  # the default; instances carry their own mode
     spec = None
     render_mode = None
     closed = False
@@ -147,6 +158,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self.similar_climate_counties = bool(similar_climate_counties)
         self.seed_mode = seed_mode
         self.autoreset = autoreset
+        self.metadata = {**type(self).metadata, "autoreset_mode": _autoreset_metadata(autoreset)}
         self.env_gid0 = int(env_gid0)
         self.write_obs = bool(write_obs)
         self._ctor_budget = budget
