@@ -267,8 +267,10 @@ def test_step64_kernel_equals_classic_kernel(dev, n, write_obs):
     old.close()
 
 
-@pytest.mark.parametrize("n,write_obs,augment", [(257, True, False), (4096 + 5, True, True), (1000, False, False), (63, True, True)])
-def test_step64_in_kernel_autoreset_equals_classic_kernel(dev, n, write_obs, augment):
+@pytest.mark.parametrize("n,write_obs,augment,fixes", [(257, True, False, ()), (4096 + 5, True, True, ()), (1000, False, False, ()),
+                                                       (63, True, True, ()),
+                                                       (2048 + 7, True, True, ("alert_2wks", "lag", "penalty", "obs", "augment"))])
+def test_step64_in_kernel_autoreset_equals_classic_kernel(dev, n, write_obs, augment, fixes):
     """Batches that are not in lock step (ragged episode lengths here; masked resets elsewhere) restart finished envs
     inside the step kernel. The 64-envs-per-wave kernel's rare per-lane epilogue (k_step64<..., AUTORESET>) against the
     4-lanes-per-env kernel's (k_step<AUTORESET>): 340 steps, every env crosses two or three episode boundaries at its
@@ -280,7 +282,8 @@ def test_step64_in_kernel_autoreset_equals_classic_kernel(dev, n, write_obs, aug
     rng = np.random.default_rng(n)
     sd.meta["n_days_per_episode"] = rng.integers(120, 154, size=(20, 3))
     ct = tables.compile_from_synth(sd)
-    kw = dict(tables=ct, device=dev, write_obs=write_obs, similar_climate_counties=augment, env_gid0=77, lockstep=False)
+    kw = dict(tables=ct, device=dev, write_obs=write_obs, similar_climate_counties=augment, env_gid0=77, lockstep=False,
+              fixes=fixes)  # with corrected-semantics flags: the FIXES variants of both kernels
     new, old = HeatAlertVecEnv(n, step_kernel="wide", **kw), HeatAlertVecEnv(n, step_kernel="classic", **kw)
     assert new.step_kernel_name == "k_step64" and old.step_kernel_name == "k_step" and new._dev_auto and old._dev_auto
     opts = {"sample_budget": True, "sample_budget_type": "centered"}
@@ -885,12 +888,15 @@ def test_rollout_evaluates_consecutive_episodes_in_lockstep(dev):
     env.close()
 
 
+@pytest.mark.parametrize("kernel", ["classic", "wide", "unpacked"])
 @pytest.mark.parametrize("fixes", [("alert_2wks",), ("lag",), ("penalty",), ("obs",),
                                    ("alert_2wks", "lag", "penalty", "obs")])
-def test_corrected_semantics_flags(dev, fixes):
+def test_corrected_semantics_flags(dev, fixes, kernel):
     """faithful=False flags: each correction alone and all together against the
-    oracle's statement of the same correction, and each one really changes the trajectory."""
-    from weather2alert_amd import HeatAlertVecEnv
+    oracle's statement of the same correction, and each one really changes the trajectory; on the 4-lanes-per-env
+    kernel (k_step<..., FIXES>) and on the 64-envs-per-wave kernel's FIXES variants (packed lock-step state and
+    canonical state)."""
+    from weather2alert_amd import HeatAlertVecEnv, _ffi
 
     sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=6, seed=31)
     ct = tables.compile_from_synth(sd)
@@ -901,9 +907,13 @@ def test_corrected_semantics_flags(dev, fixes):
     county = rng.integers(0, ct.S, n)
     ep = dict(county_w=ct.fips_to_weather[county].astype(np.int64), year_i=rng.integers(0, ct.Y, n), coef_col=county,
               sample=rng.integers(0, ct.n_samples, n), budget=rng.integers(0, 6, n))
-    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", fixes=fixes)
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", fixes=fixes,
+                          step_kernel="wide" if kernel == "unpacked" else kernel)
+    assert env.step_kernel_name == ("k_step" if kernel == "classic" else "k_step64")
     ref = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled")
     obs, _ = env.reset(options={"episodes": ep})
+    if kernel == "unpacked":  # the 64-envs-per-wave kernel on the canonical state words (reset() recomputes the flags)
+        env._step_flags |= _ffi.STEP_UNPACKED
     ref.reset(options={"episodes": ep})
     obs_o = V.reset(ep["county_w"], ep["year_i"], ep["coef_col"], ep["sample"], ep["budget"])
     np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
@@ -919,6 +929,7 @@ def test_corrected_semantics_flags(dev, fixes):
         np.testing.assert_array_equal(obs.cpu().numpy(), obs_o.astype(np.float32))
         differs |= (not torch.equal(obs, obs_f)) or (not torch.equal(r, r_f))
     assert differs
+    assert env.packed_state == (kernel == "wide")
     env.close()
     ref.close()
 

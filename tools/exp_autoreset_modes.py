@@ -20,7 +20,9 @@ g = torch.Generator(device=dev).manual_seed(1)
 pool = [(torch.rand(n, device=dev, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
 for name, kw in (("lock step, host-launched reset (k_step64, packed state)", dict()),
                  ("lock step, classic kernel", dict(step_kernel="classic")),
-                 ("lockstep=False: in-kernel autoreset", dict(lockstep=False))):
+                 ("lockstep=False: in-kernel autoreset", dict(lockstep=False)),
+                 ("corrected semantics (faithful=False), lock step", dict(faithful=False)),
+                 ("corrected semantics except the observation fix", dict(fixes={"alert_2wks", "lag", "penalty", "augment", "budget"}))):
     env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, **kw)
     env.reset(seed=0)
     for i in range(160):

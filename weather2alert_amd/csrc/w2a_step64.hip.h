@@ -29,14 +29,16 @@
 // env.py:242-256 for one env from its packed state and today's action: budget gate, history, termination.
 // Shared by k_step64 and k_posterior_mean (which must agree on `actual` and the run-time fields).
 struct Day {
-  uint32_t t, used, streak, hist, ndays, atb, actual, used2, hist2, st_bits;
-  int32_t budget;
+  uint32_t t, used, streak, hist, ndays, atb, actual, used2, hist2, st_bits, last;
+  int32_t budget, act;
   bool done;
 };
 __device__ __forceinline__ Day derive_day(const u3 h, const u3 c, int32_t act) {
   Day d;
   d.st_bits = 0;
   if (act != 0 && act != 1) { d.st_bits |= W2A_ST_BAD_ACTION; act = 1; }
+  d.act = act;                      // the action as the step uses it (a bad one counts as 1)
+  d.last = D0_LAST(h.a);            // yesterday's granted alert
   d.t = D0_T(h.a); d.used = D0_USED(h.a); d.streak = D0_STREAK(h.a);
   d.hist = D1_HIST(h.b); d.ndays = D1_NDAYS(h.b);
   d.budget = (int32_t)c.a;
@@ -50,14 +52,24 @@ __device__ __forceinline__ Day derive_day(const u3 h, const u3 c, int32_t act) {
 }
 // env.py:190-193 as the row's run-time slots 24..27: alert_lag1 = today's action for t > 0 (Q3), streak before
 // today's action (Q4), remaining budget after it, the agent's 14-day count (Q1)
-__device__ __forceinline__ float4 runtime_fields(const Day &d) {
-  return make_float4((d.t > 0) ? (float)d.actual : 0.0f, (float)d.streak, (float)(d.budget - (int32_t)d.used2),
-                     (float)__popc(d.hist2));
+__device__ __forceinline__ float4 runtime_fields(const Day &d, bool fix_lag = false) {
+  // W2A_FIX_LAG: alert_lag1 is yesterday's granted alert instead of today's (Q3)
+  return make_float4((d.t > 0) ? (float)(fix_lag ? d.last : d.actual) : 0.0f, (float)d.streak,
+                     (float)(d.budget - (int32_t)d.used2), (float)__popc(d.hist2));
+}
+// overwrite component `idx` (0..3) of a float4 without dynamic register indexing
+__device__ __forceinline__ void set_comp4(float4 &x, int idx, float v) {
+  if (idx == 0) x.x = v;
+  if (idx == 1) x.y = v;
+  if (idx == 2) x.z = v;
+  if (idx == 3) x.w = v;
 }
 
-struct S64Wave {
+template <bool FIXES>
+struct S64WaveT {
   uint2 desc[S64_ENVS];             // {float4 index of the feature row, float4 index of the coefficient rows | need_eff << 31}
   float4 rt[S64_ENVS];              // run-time fields alert_lag1, alert_streak, remaining_budget, alert_2wks (slots 24..27)
+  float4 rt2[FIXES ? S64_ENVS : 1]; // FIXES / W2A_FIX_OBS: the same fields as the NEXT day's observation shows them
   float2 z[S64_ENVS];               // {(float) baseline logit, (float) effectiveness logit (-inf: gate closed)}
   float tile[S64_PASS_ENVS * ROWF]; // packed observation rows of one pass (+ scratch words behind them)
 };
@@ -100,8 +112,10 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 // AUTORESET: same-step autoreset for batches that are not in lock step (masked resets, ragged episode lengths): an env
 // whose terminal step has just run draws its next episode and gets that episode's first observation, as in
 // k_step<AUTORESET> -- here as a rare per-lane epilogue (one env-day in n_days), on the canonical state words.
-template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED, bool AUTORESET = false>
-__device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const int lane, const int64_t wave_env0,
+// FIXES: the corrected-semantics flags of a.tb.fixes (W2A_FIX_*: Q1 agent's 14-day count into the historical column,
+// Q3 true lag, Q5 live over-budget penalty, Q6 observation of the day the next action applies to), as in k_step<..., FIXES>.
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED, bool AUTORESET = false, bool FIXES = false>
+__device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw, const int lane, const int64_t wave_env0,
                                          const bool valid, const uint32_t e, const u3 h, const u3 c, const int32_t act,
                                          const int4 so) {
   // ---------------------------------------------------------------- phase A: lane = env
@@ -110,6 +124,8 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   const uint32_t actual = d.actual, atb = d.atb, st_bits = d.st_bits;
   const int32_t budget = d.budget;
   const bool done = d.done;
+  const uint32_t fx = FIXES ? a.tb.fixes : 0u;
+  const bool fix_obs = FIXES && WRITE_OBS && (fx & W2A_FIX_OBS);
   // The effectiveness logit enters the reward through eff * gate * actual (env.py:218-221): its coefficient row is
   // fetched only for envs that alert today AND whose gate is open. The gate flag of (day, row) comes from a 1 KB
   // per-day bitmap (L2-resident) when the tables carry one; without it every alerting env fetches the row and the
@@ -122,8 +138,13 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
     // sizes are validated in w2a_create). The effectiveness row is fetched only on alert days (k_step).
     const uint32_t day_row = t * (uint32_t)(a.tb.S_w * a.tb.Y) + c.b;
     const uint32_t wrow = W_COL(c.c) * (uint32_t)a.tb.n_samples + W_SAMPLE(c.c);
-    sw.desc[lane] = make_uint2(day_row * (ROWF / 4), (wrow * (2 * ROWF / 4)) | (need_eff << 31));
-    sw.rt[lane] = runtime_fields(d);
+    // bit 31 of the row index (FIXES only): the observation is the NEXT day's row (W2A_FIX_OBS, not on the terminal step)
+    sw.desc[lane] = make_uint2((day_row * (ROWF / 4)) | ((fix_obs && !done) ? 0x80000000u : 0u),
+                               (wrow * (2 * ROWF / 4)) | (need_eff << 31));
+    sw.rt[lane] = runtime_fields(d, (fx & W2A_FIX_LAG) != 0u);
+    if (fix_obs)  // env.py:190-193 after today's action: lag = today's alert, the updated streak
+      sw.rt2[FIXES ? lane : 0] = make_float4((float)actual, (float)(actual ? streak + 1 : 0), (float)(budget - (int32_t)used2),
+                                 (float)__popc(hist2));
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -133,19 +154,25 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
   const int p = lane & 7;   // float4 of the row owned by this lane
   const int g = lane >> 3;  // row group: env j = pass * 32 + round * 8 + g of the wave
   const int n_obs = a.tb.n_obs;
-  const bool write_me = valid && !done;  // a finished env keeps its stale observation (env.py:257-262, Q6)
+  // a finished env keeps its stale observation (env.py:257-262, Q6); W2A_FIX_OBS writes the last row instead
+  const bool write_me = valid && (!done || fix_obs);
+  const uint32_t next_day = (uint32_t)(a.tb.S_w * a.tb.Y) * (ROWF / 4);  // float4 index distance to the next day's row
 #pragma unroll 1
   for (int pass = 0; pass < S64_ENVS / S64_PASS_ENVS; ++pass) {
     if (REWARD_GIVEN && !WRITE_OBS) break;               // nothing to gather at all
     if (wave_env0 + pass * S64_PASS_ENVS >= a.n) break;  // wave-uniform
-    float4 x[S64_ROUNDS], wb[S64_ROUNDS], we[S64_ROUNDS];
-    bool need[S64_ROUNDS];
+    float4 x[S64_ROUNDS], wb[S64_ROUNDS], we[S64_ROUNDS], xo[FIXES ? S64_ROUNDS : 1];
+    bool need[S64_ROUNDS], nxt[S64_ROUNDS];
 #pragma unroll
     for (int r = 0; r < S64_ROUNDS; ++r) {
-      const uint2 ds = sw.desc[pass * S64_PASS_ENVS + r * 8 + g];
+      uint2 ds = sw.desc[pass * S64_PASS_ENVS + r * 8 + g];
       need[r] = (ds.y >> 31) != 0u;
+      nxt[r] = FIXES && (ds.x >> 31) != 0u;
+      if (FIXES) ds.x &= 0x7FFFFFFFu;
       const uint32_t wq = ds.y & 0x7FFFFFFFu;
       x[r] = a.tb.X[ds.x + p];
+      // W2A_FIX_OBS: the row the observation shows (the next day's; the same line again where it is today's)
+      if (fix_obs) xo[r] = a.tb.X[ds.x + (nxt[r] ? next_day : 0u) + p];
       wb[r] = we[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!REWARD_GIVEN) {
         wb[r] = a.tb.W[wq + p];
@@ -160,6 +187,13 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
     for (int r = 0; r < S64_ROUNDS; ++r) {
       const int j = pass * S64_PASS_ENVS + r * 8 + g;
       if (p == RT_QUAD) x[r] = sw.rt[j];
+      if (FIXES && (fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0) {
+        // the agent's 14-day count also replaces the historical 'alerts_2wks' column, so it feeds the reward (Q1)
+        const float a2w = sw.rt[j].w;
+        if (p == (a.tb.slot_hist2w >> 2)) set_comp4(x[r], a.tb.slot_hist2w & 3, a2w);
+        if (fix_obs && p == (a.tb.slot_hist2w >> 2)) set_comp4(xo[r], a.tb.slot_hist2w & 3, a2w);
+      }
+      if (fix_obs && p == RT_QUAD) xo[r] = nxt[r] ? sw.rt2[FIXES ? j : 0] : sw.rt[j];
       if (!REWARD_GIVEN) {
       // env.py:207-217: two 28-term dot products, fp64 accumulation (products of f32 values are exact in fp64)
       const double x0 = (double)x[r].x, x1 = (double)x[r].y, x2 = (double)x[r].z, x3 = (double)x[r].w;
@@ -193,10 +227,11 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
         // branch-free scatter into the packed tile; slots that are not observation columns go to scratch words
         const int base = (r * 8 + g) * n_obs;
         const int trash = S64_PASS_ENVS * n_obs + (lane & 31);
-        sw.tile[so.x >= 0 ? base + so.x : trash] = x[r].x;
-        sw.tile[so.y >= 0 ? base + so.y : trash] = x[r].y;
-        sw.tile[so.z >= 0 ? base + so.z : trash] = x[r].z;
-        sw.tile[so.w >= 0 ? base + so.w : trash] = x[r].w;
+        const float4 ov = fix_obs ? xo[FIXES ? r : 0] : x[r];
+        sw.tile[so.x >= 0 ? base + so.x : trash] = ov.x;
+        sw.tile[so.y >= 0 ? base + so.y : trash] = ov.y;
+        sw.tile[so.z >= 0 ? base + so.z : trash] = ov.z;
+        sw.tile[so.w >= 0 ? base + so.w : trash] = ov.w;
       }
     }
     if (WRITE_OBS) {
@@ -259,6 +294,7 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
     const float base = sigmoid_f32(z.x);  // env.py:211-221
     const float eff = need_eff ? sigmoid_f32(z.y) : 0.0f;  // not needed = no alert or closed gate: eff * actual = 0
     r = -(1000.0f / 152.0f) * base * (1.0f - eff);
+    if (FIXES && (fx & W2A_FIX_PENALTY) && d.act == 1 && atb) r = -1.0f;  // env.py:223-224 made live (Q5)
   }
   const uint32_t t2 = done ? t : t + 1;
   const uint32_t streak2 = done ? streak : (actual ? streak + 1 : 0);  // env.py:260
@@ -299,6 +335,8 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64Wave &sw, const i
           for (int qd = 0; qd < ROWF / 4; ++qd) {
             float4 v = xr[qd];
             if (qd == RT_QUAD) v = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
+            if (FIXES && (fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && qd == (a.tb.slot_hist2w >> 2))
+              set_comp4(v, a.tb.slot_hist2w & 3, 0.0f);  // the agent's (empty) history replaces the column
             const int4 sq = reinterpret_cast<const int4 *>(a.slot_obs)[qd];
             if (sq.x >= 0) row[sq.x] = v.x;
             if (sq.y >= 0) row[sq.y] = v.y;
@@ -344,13 +382,13 @@ __device__ __forceinline__ void s64_load_state(const StepArgs &a, uint32_t e, u3
 // action streams, 28 B per env) has few bytes in flight and a full memory round trip of latency; requesting the
 // NEXT tile's words before the current tile's phases run takes that hop off the wave's critical path for every
 // tile but the first (7 more VGPRs). Measured: DESIGN.md §4.
-template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED = false, bool AUTORESET = false>
-__global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
-  __shared__ __attribute__((aligned(16))) S64Wave s_w[S64_WAVES];
+template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED = false, bool AUTORESET = false, bool FIXES = false>
+__global__ __launch_bounds__(BLOCK, FIXES ? 3 : W2A_S64_MIN_WAVES) void k_step64(const StepArgs a) {
+  __shared__ __attribute__((aligned(16))) S64WaveT<FIXES> s_w[S64_WAVES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  S64Wave &sw = s_w[wave];
+  S64WaveT<FIXES> &sw = s_w[wave];
   const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
   const int64_t wave_env0 = ((int64_t)lb * S64_WAVES + wave) * (S64_ENVS * W2A_S64_TILES);
   if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no workgroup barrier is used below
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(BLOCK, W2A_S64_MIN_WAVES) void k_step64(const StepA
       if (PACKED) s64_load_packed(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
       else s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
     }
-    s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED, AUTORESET>(a, sw, lane, env0, valid, e, h, c, act, so);
+    s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED, AUTORESET, FIXES>(a, sw, lane, env0, valid, e, h, c, act, so);
     // the per-wave LDS record is rewritten by the next tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -55,7 +55,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
-  if (wide && !env->tb.fixes && !(flags & W2A_STEP_CLASSIC)) {
+  if (wide && !(flags & W2A_STEP_CLASSIC)) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
     const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
@@ -70,7 +70,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
         env->pk_valid = 1;
       }
       a.uni_t = env->uni_t; a.uni_nd = env->uni_nd;
-      if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
+      if (env->tb.fixes) {  // corrected-semantics flags: their own variants, the faithful kernels carry none of the code
+        if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, false, true>), grid64, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step64<true, false, true, false, true>), grid64, block, 0, s, a);
+      } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
       HIP_TRY(hipGetLastError());
       env->canon_valid = 0;
@@ -84,6 +87,14 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     if (given) {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
+    } else if (env->tb.fixes) {
+      if (autoreset) {
+        if (no_obs) hipLaunchKernelGGL((k_step64<false, false, false, true, true>), grid64, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step64<true, false, false, true, true>), grid64, block, 0, s, a);
+      } else {
+        if (no_obs) hipLaunchKernelGGL((k_step64<false, false, false, false, true>), grid64, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step64<true, false, false, false, true>), grid64, block, 0, s, a);
+      }
     } else if (autoreset) {  // batches that left lock step: the finished envs restart inside the kernel (rare epilogue)
       if (no_obs) hipLaunchKernelGGL((k_step64<false, false, false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false, false, true>), grid64, block, 0, s, a);

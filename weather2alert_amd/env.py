@@ -319,7 +319,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         """The step kernel w2a_step launches for this env right now (mirrors the dispatch in csrc/w2a_kernels.hip)."""
         wide = self._pm or self.step_kernel == "wide" or (self.step_kernel == "auto" and
                                                           self.num_envs >= _ffi.S64_MIN_ENVS)
-        return "k_step64" if (wide and not (self.fixes - {"budget"}) and self.step_kernel != "classic") else "k_step"
+        return "k_step64" if (wide and self.step_kernel != "classic") else "k_step"
 
     @property
     def packed_state(self) -> bool:
