@@ -2,7 +2,8 @@
 """Randomised parity sweep on the GPU: random table shapes, batch sizes around every tile boundary, random policies and
 budgets -- every step kernel form (4-lanes-per-env, 64-envs-per-wave on the canonical and on the packed state), both
 sampled-reward rollout kernels (k_rollout64, k_rollout_mfma) and the three posterior-mean kernels against the float64
-oracle (oracle/heatalert_oracle.py; test infrastructure, used here as the checker only).
+oracle; every other case also the in-kernel autoreset with random corrected-semantics flags, 64-envs-per-wave kernel
+against 4-lanes-per-env kernel (oracle/heatalert_oracle.py; test infrastructure, used here as the checker only).
 
     python tools/stress_parity.py [--cases 40] [--seed 0]
 
@@ -137,6 +138,32 @@ def run_case(i, rng, dev):
         worst_pm = max(worst_pm, float(np.abs(r.cpu().numpy().astype(np.float64) - r_o).max()))
     assert worst_pm <= 1e-5, (desc, "posterior_mean", pmk, worst_pm)
     e4.close()
+    # ---- in-kernel same-step autoreset (+ a random set of corrected-semantics flags): the 64-envs-per-wave kernel's
+    # epilogue / FIXES variants against the 4-lanes-per-env kernel's, ragged episode lengths, envs restarting on their own
+    if i % 2 == 0:
+        sd2 = synth.make_synth("linear", n_fips=n_fips, years=years, n_samples=n_samples, n_days=n_days, seed=seed & 0xFFFF,
+                               extra_confounder_fips=2)
+        sd2.meta["n_days_per_episode"] = rng.integers(max(n_days - 30, 2), n_days + 1, size=(n_fips, len(years)))
+        ct2 = tables.compile_from_synth(sd2)
+        fx = tuple(f for f in ("alert_2wks", "lag", "penalty", "obs", "augment") if rng.random() < 0.3)
+        kw2 = dict(tables=ct2, device=dev, env_gid0=gid0, similar_climate_counties=augment or "augment" in fx, lockstep=False, fixes=fx)
+        ea, eb = HeatAlertVecEnv(n, step_kernel="wide", **kw2), HeatAlertVecEnv(n, step_kernel="classic", **kw2)
+        oa, _ = ea.reset(seed=seed)
+        ob, _ = eb.reset(seed=seed)
+        assert torch.equal(oa, ob), (desc, "autoreset reset obs", fx)
+        for t in range(int(rng.integers(n_days, 2 * n_days + 20))):
+            at = torch.as_tensor((rng.random(n) < p_act).astype(np.int32), device=dev)
+            oa, ra, da, _, _ = ea.step(at)
+            ob, rb, db, _, _ = eb.step(at)
+            assert torch.equal(oa, ob) and torch.equal(da, db), (desc, "autoreset obs/done", fx, t)
+            assert torch.allclose(ra, rb, rtol=0, atol=1e-6), (desc, "autoreset reward", fx, t)
+        sa, sb = ea.state(), eb.state()
+        for k in sa:
+            if k != "episode_return":
+                assert torch.equal(sa[k], sb[k]), (desc, "autoreset state", k, fx)
+        assert ea.check_status() == eb.check_status() == 0, (desc, fx)
+        ea.close()
+        eb.close()
     print(f"{desc} steps={steps} policy={kindp} rollout={used_mfma} pm={pmk}: reward {worst:.2e}, posterior mean {worst_pm:.2e}",
           flush=True)
     return worst, worst_pm, used_mfma
