@@ -58,7 +58,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          seeded with seed+i), bit-identical episode tuples to the reference.
     autoreset            "same_step" (finished envs restart inside the same step() call and the
                          returned observation is the new episode's first one; the finished
-                         episode's return is in info["final_return"]) or "disabled".
+                         episode's return is in info["final_return"]) or "disabled". same_step is what SB3's
+                         DummyVecEnv does around the reference env and Gymnasium's AutoresetMode.SAME_STEP
+                         (``metadata["autoreset_mode"]``). No ``final_obs`` is returned: the reference's terminal
+                         step hands back the PREVIOUS step's observation unchanged (env.py:257-262, Q6), i.e. a row
+                         the caller already holds, and episodes end by termination only (no truncation to
+                         bootstrap from). Gymnasium's NEXT_STEP mode is not offered; use "disabled" and reset()
+                         with a mask for other schedules.
     reward_path          "gather" (or "auto"): each step gathers the env's coefficient rows and sums the 28 terms. The
                          precomputed logit-table path of round 1 ("table") was removed: it was slower at every batch
                          size (each 16-B logit pair dragged a cold 128-B line of a 2 GB table).
