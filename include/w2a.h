@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 14
+#define W2A_ABI_VERSION 15
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -60,6 +60,10 @@ enum {
                              >= 131 072 envs, the 4-lanes-per-env kernel smaller ones: the faster one on MI355X) */
   W2A_STEP_UNPACKED = 128, /* do not use the lock-step mirror of the per-env state (below; same results; for A/B
                              measurements and tests) */
+  W2A_STEP_NEXT_STEP = 256, /* with W2A_STEP_AUTORESET: the restart happens on the call AFTER the terminal step (Gymnasium's
+                             AutoresetMode.NEXT_STEP): the terminal step leaves the env finished with its stale
+                             observation; the next call ignores that env's action, draws its next episode and returns
+                             the episode's first observation with reward 0 and done 0 */
   W2A_STEP_SKIP_FINISHED = 64, /* with W2A_STEP_REWARD_GIVEN: envs whose episode is over are left untouched (reward
                              written as 0, done 1, state / return / observation unchanged, no status bit): policy
                              loops over batches that are not in lock step */

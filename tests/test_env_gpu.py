@@ -312,6 +312,131 @@ def test_step64_in_kernel_autoreset_equals_classic_kernel(dev, n, write_obs, aug
     old.close()
 
 
+@pytest.mark.parametrize("n,kernel", [(300, "auto"), (1000 + 3, "wide")])
+def test_next_step_autoreset_in_lockstep(dev, n, kernel):
+    """autoreset="next_step" (Gymnasium's AutoresetMode.NEXT_STEP) on a lock-step batch against the same batch with
+    "same_step": identical calls inside an episode; the terminal call returns done with the STALE observation (Q6)
+    instead of the next episode's first one; the following call ignores the actions and returns that first observation
+    with reward 0 and nobody done; then both continue on the same episodes. rollout() restarts a finished batch before
+    it runs; a checkpoint taken between the terminal step and the restart resumes correctly."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=14, years=[2006, 2007], n_samples=5, seed=9, n_days=61)
+    ct = tables.compile_from_synth(sd)
+    kw = dict(tables=ct, device=dev, similar_climate_counties=True, step_kernel=kernel, env_gid0=5)
+    N, S = HeatAlertVecEnv(n, autoreset="next_step", **kw), HeatAlertVecEnv(n, autoreset="same_step", **kw)
+    assert N.metadata["autoreset_mode"] == "next_step" and N._host_next and S._host_auto
+    oN, _ = N.reset(seed=3)
+    oS, _ = S.reset(seed=3)
+    assert torch.equal(oN, oS)
+    rng = np.random.default_rng(n)
+    pending, prev, first, restarts = False, oN.clone(), None, 0
+    for k in range(3 * ct.T + 7):
+        a = torch.as_tensor((rng.random(n) < 0.3).astype(np.int32), device=dev)
+        oN, rN, dN, _, _ = N.step(a)
+        if pending:  # the restart call
+            assert float(rN.abs().max()) == 0.0 and not bool(dN.any()) and torch.equal(oN, first)
+            pending, restarts, prev = False, restarts + 1, oN.clone()
+            if restarts == 1:  # a checkpoint right after a restart and one right after a terminal step (below) both resume
+                N.load_state_dict(N.state_dict())
+            continue
+        oS, rS, dS, _, _ = S.step(a)
+        assert torch.equal(dN, dS) and torch.allclose(rN, rS, rtol=0, atol=1e-6)
+        if bool(dS.all()):
+            assert torch.equal(oN, prev)  # stale terminal observation
+            first, pending = oS.clone(), True
+            assert torch.allclose(N._final_return, S._final_return, rtol=1e-6)
+            if restarts == 1:
+                N.load_state_dict(N.state_dict())
+                assert N._pending_reset
+        else:
+            assert torch.equal(oN, oS) and not bool(dS.any())
+        prev = oN.clone()
+    assert restarts == 3
+    sN, sS = N.state(), S.state()
+    for key in ("episode_no", "county_w", "year_i", "coef_col", "sample", "budget", "t", "used"):
+        assert torch.equal(sN[key], sS[key]), key
+    # rollout(): run to the end of the episode, then again -- the second call restarts the finished batch first
+    pol = dict(kind="bernoulli", p=0.1, seed=1)
+    o1, o2 = N.rollout(pol), S.rollout(pol)
+    assert N._pending_reset and torch.equal(o1["alerts"], o2["alerts"]) and bool(o1["done"].all())
+    o1, o2 = N.rollout(pol), S.rollout(pol)
+    assert torch.equal(o1["alerts"], o2["alerts"]) and torch.allclose(o1["return"], o2["return"], rtol=1e-6)
+    assert N.check_status() == S.check_status() == 0
+    N.close()
+    S.close()
+
+
+@pytest.mark.parametrize("n,fixes", [(150, ()), (257, ("lag", "obs"))])
+def test_next_step_autoreset_in_kernel(dev, n, fixes):
+    """autoreset="next_step" on batches that are not in lock step (ragged episode lengths): the restart happens inside
+    the step kernels (W2A_STEP_NEXT_STEP). Both kernels agree call by call, and per env the (episode, day) -> (reward,
+    done, observation) record equals the same_step env's, with actions fixed per (env, episode, day); restart calls
+    return reward 0, done False and the observation same_step returned on its terminal call."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=12, years=[2006, 2007], n_samples=4, seed=19, n_days=50)
+    rng = np.random.default_rng(n)
+    sd.meta["n_days_per_episode"] = rng.integers(30, 51, size=(12, 2))
+    ct = tables.compile_from_synth(sd)
+    kw = dict(tables=ct, device=dev, env_gid0=11, lockstep=False, fixes=fixes)
+    Nw = HeatAlertVecEnv(n, autoreset="next_step", step_kernel="wide", **kw)
+    Nc = HeatAlertVecEnv(n, autoreset="next_step", step_kernel="classic", **kw)
+    S = HeatAlertVecEnv(n, autoreset="same_step", step_kernel="classic", **kw)
+    assert Nw.step_kernel_name == "k_step64" and Nc.step_kernel_name == "k_step" and Nw._dev_auto
+
+    def act(st):  # the action of an env is a function of (env, episode, day)
+        e, t = st["episode_no"].cpu().numpy().astype(np.uint64), st["t"].cpu().numpy().astype(np.uint64)
+        h = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + e * np.uint64(40503) + t * np.uint64(97)) % np.uint64(1000)
+        return torch.as_tensor((h < 300).astype(np.int32), device=dev)
+
+    for E in (Nw, Nc, S):
+        E.reset(seed=8)
+    logs = {}
+    for name, E in (("next", Nw), ("same", S)):
+        log, fin = {}, np.zeros(n, bool)
+        for k in range(170):
+            st = E.state()
+            ep, t = st["episode_no"].cpu().numpy(), st["t"].cpu().numpy()
+            was_fin = st["finished"].cpu().numpy().astype(bool)
+            a = act(st)
+            o, r, d, _, _ = E.step(a)
+            if E is Nw:  # the other kernel, same calls
+                o2, r2, d2, _, _ = Nc.step(a)
+                assert torch.equal(o, o2) and torch.equal(d, d2) and torch.allclose(r, r2, rtol=0, atol=1e-6), k
+            o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy().astype(bool)
+            for i in range(n):
+                if name == "next" and was_fin[i]:  # restart call of env i
+                    assert r[i] == 0.0 and not d[i]
+                    log[(i, int(ep[i]), "restart")] = o[i].copy()
+                else:
+                    log[(i, int(ep[i]), int(t[i]))] = (float(r[i]), bool(d[i]), o[i].copy())
+        logs[name] = log
+    same, nxt = logs["same"], logs["next"]
+    checked = restarts = 0
+    term_obs = {(j, e2): v[2] for (j, e2, _), v in same.items() if v[1]}  # same_step: observation of the terminal call
+    for key, val in nxt.items():
+        i, ep, t = key
+        if t == "restart":  # = what same_step returned as observation on that episode's terminal call
+            assert np.array_equal(term_obs[(i, ep)], val)
+            restarts += 1
+        elif key in same:
+            r1, d1, o1 = val
+            r2, d2, o2 = same[key]
+            assert abs(r1 - r2) <= 1e-6 and d1 == d2
+            if not d1:
+                assert np.array_equal(o1, o2)
+            checked += 1
+    assert checked > 100 * n and restarts >= 2 * n
+    sa, sb = Nw.state(), Nc.state()
+    for key in sa:
+        if key != "episode_return":
+            assert torch.equal(sa[key], sb[key]), key
+    assert Nw.check_status() == Nc.check_status() == S.check_status() == 0
+    for E in (Nw, Nc, S):
+        E.close()
+
+
 def test_packed_lockstep_state_equals_canonical_state(dev):
     """While a batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env state
     (day / episode length / finished bit as kernel arguments) instead of the 24-B canonical words. Same arithmetic, so

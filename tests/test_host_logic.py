@@ -116,6 +116,7 @@ def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monke
         cls = m.HeatAlertVecEnv
         assert cls.metadata["autoreset_mode"] is FakeAutoresetMode.SAME_STEP and cls.spec is None and cls.render_mode is None
         assert m._autoreset_metadata("disabled") is FakeAutoresetMode.DISABLED
+        assert m._autoreset_metadata("next_step") is FakeAutoresetMode.NEXT_STEP
         for attr in ("np_random", "np_random_seed", "unwrapped"):
             assert isinstance(getattr(cls, attr), property)
         for meth in ("reset", "step", "close"):

@@ -11,9 +11,9 @@ ROW_FLOATS = 32
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED, STEP_UNPACKED = 1, 2, 8, 16, 32, 64, 128
+STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED, STEP_UNPACKED, STEP_NEXT_STEP = 1, 2, 8, 16, 32, 64, 128, 256
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 14
+ABI_VERSION = 15
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 

@@ -22,6 +22,7 @@ struct StepArgs {
   int32_t act_dtype;
   int32_t uni_t, uni_nd;  // k_step64 packed variant: the day and episode length shared by every env (lock step)
   int32_t skip_finished;  // k_step64: envs whose episode is over are left untouched (reward 0, done 1, no status bit)
+  int32_t next_step;      // AUTORESET variants: restart on the call after the terminal step (W2A_STEP_NEXT_STEP)
 };
 
 #ifndef W2A_MIN_WAVES
@@ -46,12 +47,15 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
                                           int grp, bool valid, uint32_t e, const uint4 cold, const uint4 hot,
                                           int32_t act) {
   uint32_t st_bits = 0;
+  // W2A_STEP_NEXT_STEP: an env whose terminal step ran on the previous call restarts on this one; its action is ignored
+  const bool restart_in = AUTORESET && a.next_step && D1_FIN(hot.y);
+  if (restart_in) act = 0;
   if (act != 0 && act != 1) { st_bits |= W2A_ST_BAD_ACTION; act = 1; }
 
   const uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x);
   const uint32_t hist = D1_HIST(hot.y), ndays = D1_NDAYS(hot.y);
   const int32_t budget = (int32_t)hot.w;
-  if (D1_FIN(hot.y)) st_bits |= W2A_ST_STEP_AFTER_DONE;
+  if (D1_FIN(hot.y) && !restart_in) st_bits |= W2A_ST_STEP_AFTER_DONE;
 
   // env.py:242-250  budget gate, history
   const uint32_t atb = ((int32_t)used == budget) ? 1u : 0u;
@@ -144,8 +148,9 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     }
   }
   if (AUTORESET) {
-    if (done) {
-      // same-step autoreset: draw the next episode, emit its first observation (env.py:162-181)
+    if (a.next_step ? restart_in : done) {
+      // same-step autoreset (or, W2A_STEP_NEXT_STEP, the call after the terminal step): draw the next episode, emit
+      // its first observation (env.py:162-181)
       Episode ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
       if (ep.bad) st_bits |= W2A_ST_BAD_EPISODE;
       cold2 = make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1);
@@ -161,11 +166,11 @@ __device__ __forceinline__ void step_tile(const StepArgs &a, float *s_tile_wave,
     }
   }
   if (valid && l == 0) {
-    if (AUTORESET && done) store_episode(a.st, e, cold2, hot2);
+    if (AUTORESET && (a.next_step ? restart_in : done)) store_episode(a.st, e, cold2, hot2);
     else store_hot(a.st, e, hot2);
-    a.reward[e] = r;
-    a.done[e] = done ? 1 : 0;
-    if (done) {
+    a.reward[e] = restart_in ? 0.0f : r;                 // the restarting call is no env step: reward 0, not done
+    a.done[e] = (done && !restart_in) ? 1 : 0;
+    if (done && !restart_in) {
       if (a.last_return) a.last_return[e] = ret;
     }
     if (st_bits) atomicOr(a.status, (int)st_bits);

@@ -124,6 +124,9 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   const uint32_t actual = d.actual, atb = d.atb, st_bits = d.st_bits;
   const int32_t budget = d.budget;
   const bool done = d.done;
+  // W2A_STEP_NEXT_STEP: an env whose terminal step ran on the previous call restarts on this one (epilogue below); the
+  // call is no env step for it: reward 0, not done, no status bit, its action ignored
+  const bool restart_in = AUTORESET && a.next_step && D1_FIN(h.b);
   const uint32_t fx = FIXES ? a.tb.fixes : 0u;
   const bool fix_obs = FIXES && WRITE_OBS && (fx & W2A_FIX_OBS);
   // The effectiveness logit enters the reward through eff * gate * actual (env.py:218-221): its coefficient row is
@@ -155,7 +158,7 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   const int g = lane >> 3;  // row group: env j = pass * 32 + round * 8 + g of the wave
   const int n_obs = a.tb.n_obs;
   // a finished env keeps its stale observation (env.py:257-262, Q6); W2A_FIX_OBS writes the last row instead
-  const bool write_me = valid && (!done || fix_obs);
+  const bool write_me = valid && (!done || fix_obs) && !restart_in;
   const uint32_t next_day = (uint32_t)(a.tb.S_w * a.tb.Y) * (ROWF / 4);  // float4 index distance to the next day's row
 #pragma unroll 1
   for (int pass = 0; pass < S64_ENVS / S64_PASS_ENVS; ++pass) {
@@ -280,7 +283,10 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   }
 
   // ---------------------------------------------------------------- phase C: lane = env
-  if (valid && a.skip_finished && D1_FIN(h.b)) {
+  if (AUTORESET && valid && restart_in) {
+    a.reward[e] = 0.0f;
+    a.done[e] = 0;
+  } else if (valid && a.skip_finished && D1_FIN(h.b)) {
     // W2A_STEP_SKIP_FINISHED: policy loops over batches that are not in lock step (w2a_policy_actions gave this env
     // action 0): the finished episode's state, return and observation stay as they are
     a.reward[e] = 0.0f;
@@ -320,7 +326,7 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
     // env.py:162-181 for the envs that finished today: next episode from the device RNG (draw_episode, the k_reset /
     // k_step<AUTORESET> code), its state words over the ones phase C has just written, its day-0 row as the returned
     // observation (the pass flush left the finished env's row alone)
-    const bool rs = valid && done;
+    const bool rs = valid && (a.next_step ? restart_in : done);
     if (__any(rs)) {
       if (rs) {
         const uint4 cold = load_cold(a.st, e);

@@ -26,6 +26,8 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   a.actions = actions; a.obs = obs; a.reward = reward; a.done = done; a.last_return = last_return;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0; a.rc = env->autoreset; a.act_dtype = action_dtype;
   a.skip_finished = (flags & W2A_STEP_SKIP_FINISHED) ? 1 : 0;
+  a.next_step = (flags & W2A_STEP_NEXT_STEP) ? 1 : 0;
+  if (a.next_step && !autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_NEXT_STEP goes with W2A_STEP_AUTORESET");
   if (a.skip_finished && !given)
     return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_SKIP_FINISHED goes with W2A_STEP_REWARD_GIVEN (policy loops)");
   dim3 grid(grid_for(env->n)), block(BLOCK);

@@ -42,7 +42,8 @@ def _autoreset_metadata(mode: str):
     """metadata["autoreset_mode"]: gymnasium's AutoresetMode member when the package has one, else the plain string."""
     if _AutoresetMode is None:
         return mode
-    return {"same_step": _AutoresetMode.SAME_STEP, "disabled": _AutoresetMode.DISABLED}[mode]
+    return {"same_step": _AutoresetMode.SAME_STEP, "next_step": _AutoresetMode.NEXT_STEP,
+            "disabled": _AutoresetMode.DISABLED}[mode]
 
 
 class HeatAlertVecEnv(_VectorEnvBase):
@@ -63,8 +64,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          (``metadata["autoreset_mode"]``). No ``final_obs`` is returned: the reference's terminal
                          step hands back the PREVIOUS step's observation unchanged (env.py:257-262, Q6), i.e. a row
                          the caller already holds, and episodes end by termination only (no truncation to
-                         bootstrap from). Gymnasium's NEXT_STEP mode is not offered; use "disabled" and reset()
-                         with a mask for other schedules.
+                         bootstrap from). "next_step" is Gymnasium's AutoresetMode.NEXT_STEP (what
+                         SyncVectorEnv does by default around the reference env): the terminal step returns done =
+                         True with the stale observation; on the NEXT call a finished env ignores its action, starts
+                         its next episode and returns that episode's first observation with reward 0 and done =
+                         False. Per env the sequence of episodes is the same as with "same_step" (device seed mode
+                         only).
     reward_path          "gather" (or "auto"): each step gathers the env's coefficient rows and sums the 28 terms. The
                          precomputed logit-table path of round 1 ("table") was removed: it was slower at every batch
                          size (each 16-B logit pair dragged a cold 128-B line of a 2 GB table).
@@ -133,7 +138,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         split: str = "65k",
         device: str | torch.device = "cuda:0",
         seed_mode: Literal["device", "numpy_parity"] = "device",
-        autoreset: Literal["same_step", "disabled"] = "same_step",
+        autoreset: Literal["same_step", "next_step", "disabled"] = "same_step",
         tables: CompiledTables | DeviceTables | None = None,
         env_gid0: int = 0,
         write_obs: bool = True,
@@ -158,8 +163,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
             raise ValueError("num_envs must be positive")
         if seed_mode not in ("device", "numpy_parity"):
             raise ValueError(f"seed_mode {seed_mode!r}")
-        if autoreset not in ("same_step", "disabled"):
+        if autoreset not in ("same_step", "next_step", "disabled"):
             raise ValueError(f"autoreset {autoreset!r}")
+        if autoreset == "next_step" and seed_mode != "device":
+            raise ValueError("autoreset='next_step' needs seed_mode='device'")
         self.num_envs = int(num_envs)
         self.similar_climate_counties = bool(similar_climate_counties)
         self.seed_mode = seed_mode
@@ -270,6 +277,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._episode_len = int(nd[0]) if uniform else 0
         self._lockstep = bool(uniform and self.seed_mode == "device" and lockstep is not False)
         self._steps_in_episode = 0
+        self._pending_reset = False  # next_step autoreset in lock step: the terminal step has run, the next call restarts
         self._reset_cfg = None
         self._set_step_mode()
         self._w2a_step = self._lib.w2a_step
@@ -307,8 +315,14 @@ class HeatAlertVecEnv(_VectorEnvBase):
     # ------------------------------------------------------------------ plumbing
     def _set_step_mode(self):
         """in-kernel autoreset only when the batch is not in lock step (device seed mode)."""
-        self._dev_auto = self.autoreset == "same_step" and self.seed_mode == "device" and not self._lockstep
-        self._host_auto = self.autoreset == "same_step" and self.seed_mode == "device" and self._lockstep
+        auto = self.autoreset in ("same_step", "next_step") and self.seed_mode == "device"
+        self._dev_auto = auto and not self._lockstep
+        # lock step: the host counts days and launches the reset kernel right after the terminal step (same_step) or at
+        # the start of the following call (next_step: _pending_reset)
+        self._host_auto = auto and self._lockstep and self.autoreset == "same_step"
+        self._host_next = auto and self._lockstep and self.autoreset == "next_step"
+        if not self._host_next:
+            self._pending_reset = False  # envs left finished by a terminal step restart inside the kernel from here on
         if self.reward_mode == "posterior_mean" and self._dev_auto:
             raise ValueError("reward_mode='posterior_mean' cannot run with the in-kernel autoreset (batches that left "
                              "lock step); use autoreset='disabled' or whole-batch resets")
@@ -318,7 +332,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_WIDE if self.step_kernel == "wide" else 0) |
                             (_ffi.STEP_UNPACKED if self.step_kernel == "unpacked" else 0) |
-                            (_ffi.STEP_AUTORESET if self._dev_auto else 0))
+                            (_ffi.STEP_AUTORESET if self._dev_auto else 0) |
+                            (_ffi.STEP_NEXT_STEP if self._dev_auto and self.autoreset == "next_step" else 0))
 
     @property
     def step_kernel_name(self) -> str:
@@ -399,7 +414,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
             "reward": self._reward.clone(), "done": self._done.clone(),
             "host": {"sticky": list(self._sticky), "steps_in_episode": self._steps_in_episode,
                      "lockstep": self._lockstep, "reset_cfg": self._reset_cfg, "last_opts": dict(self._last_opts),
-                     "needs_reset": self._needs_reset, "info_location": list(getattr(self, "_info_location", [])),
+                     "needs_reset": self._needs_reset, "pending_reset": self._pending_reset, "info_location": list(getattr(self, "_info_location", [])),
                      "num_envs": self.num_envs, "env_gid0": self.env_gid0,
                      # pm_kernel="auto" measures; a resumed run must compute rewards with the same kernel to stay
                      # bit-exact with the run it continues (the kernels agree to ~1e-7, not to the last bit)
@@ -427,6 +442,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if h["info_location"]:
             self._info_location = list(h["info_location"])
         self._set_step_mode()
+        self._pending_reset = bool(h.get("pending_reset", False)) and self._host_next
         if self._reset_cfg is not None:
             with torch.cuda.device(self.device):
                 _ffi.check(self._lib.w2a_set_autoreset(self._h, *self._reset_cfg), "w2a_set_autoreset")
@@ -463,7 +479,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
             self._set_step_mode()
         if "episodes" in options:
             self._reset_tuples(options["episodes"], mask_t, obs_ptr)
-            if self.seed_mode == "device" and self.autoreset == "same_step":
+            if self.seed_mode == "device" and self.autoreset in ("same_step", "next_step"):
                 # later episodes of these envs come from the device RNG (in-kernel autoreset)
                 self._reset_cfg = self._device_cfg(seed, self._last_opts)
                 with torch.cuda.device(self.device):
@@ -599,6 +615,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 if obs_ptr is not None:
                     _ffi.check(lib.w2a_observe(self._h, obs_ptr, st), "w2a_observe")
         self._steps_in_episode = 0
+        self._pending_reset = False
         self._regroup()
 
     def _regroup(self):
@@ -650,6 +667,14 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if _cur_device() != self._dev_index:  # kernels launch on the current device: it must be this env's
             with torch.cuda.device(self.device):
                 return self.step(actions)
+        if self._pending_reset:
+            # autoreset="next_step" in lock step: the previous call was the terminal step of every env, so this call is
+            # their restart -- actions ignored, first observations of the next episodes, reward 0, nobody done
+            self._launch_device_reset(None, self._obs_ptr)
+            self._reward.zero_()
+            self._done.zero_()
+            self._keep_act = actions
+            return self._obs, self._reward, self._done_bool, self._truncated, _LazyInfo(self)
         if self._pm:  # today's reward of every env as the mean over all posterior draws, from the pre-step state
             rc = self._lib.w2a_posterior_mean_reward(self._h, actions.data_ptr(), _ACT_CODES[actions.dtype],
                                                      self._rew_ptr, self._stream())
@@ -665,6 +690,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
             self._steps_in_episode += 1
             if self._steps_in_episode == self._episode_len:
                 self._launch_device_reset(None, self._obs_ptr)
+        elif self._host_next:  # ... or leaves it to the next call
+            self._steps_in_episode += 1
+            if self._steps_in_episode == self._episode_len:
+                self._pending_reset = True
         elif self.autoreset == "same_step" and not self._dev_auto:
             d = done.cpu().numpy()
             if d.any():  # host-side autoreset (numpy_parity): fresh global-RNG seeds like reset(seed=None)
@@ -692,6 +721,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
         reset, so consecutive calls evaluate consecutive episodes."""
         if self._needs_reset:
             raise RuntimeError("call reset() before rollout()")
+        if self._pending_reset:  # next_step autoreset in lock step: the finished batch restarts before anything runs
+            self._launch_device_reset(None, self._obs_ptr)
         ct = self.ct
         kind = policy.get("kind")
         if kind not in _ffi.POLICY_KINDS:
@@ -757,10 +788,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
             out["n_days"], out["budget"] = st["n_days"], st["budget"]
             out["first_day"] = st0["t"]           # day index this call started from (0 for whole episodes)
             out["year"] = torch.as_tensor(ct.years, dtype=torch.int32, device=dev)[st["year_i"].long()]
-        if self._host_auto:
+        if self._host_auto or self._host_next:
             self._steps_in_episode = min(self._steps_in_episode + steps, self._episode_len)
             if self._steps_in_episode >= self._episode_len:
-                self._launch_device_reset(None, self._obs_ptr)
+                if self._host_auto:
+                    self._launch_device_reset(None, self._obs_ptr)
+                else:
+                    self._pending_reset = True
         return out
 
     def _rollout_posterior_mean(self, p, steps, out, mask, amask, words, snap, st0) -> int:
