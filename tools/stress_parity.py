@@ -146,7 +146,9 @@ def run_case(i, rng, dev):
         sd2.meta["n_days_per_episode"] = rng.integers(max(n_days - 30, 2), n_days + 1, size=(n_fips, len(years)))
         ct2 = tables.compile_from_synth(sd2)
         fx = tuple(f for f in ("alert_2wks", "lag", "penalty", "obs", "augment") if rng.random() < 0.3)
-        kw2 = dict(tables=ct2, device=dev, env_gid0=gid0, similar_climate_counties=augment or "augment" in fx, lockstep=False, fixes=fx)
+        mode = str(rng.choice(["same_step", "next_step"]))
+        kw2 = dict(tables=ct2, device=dev, env_gid0=gid0, similar_climate_counties=augment or "augment" in fx, lockstep=False, fixes=fx,
+                   autoreset=mode)
         ea, eb = HeatAlertVecEnv(n, step_kernel="wide", **kw2), HeatAlertVecEnv(n, step_kernel="classic", **kw2)
         oa, _ = ea.reset(seed=seed)
         ob, _ = eb.reset(seed=seed)
@@ -155,7 +157,7 @@ def run_case(i, rng, dev):
             at = torch.as_tensor((rng.random(n) < p_act).astype(np.int32), device=dev)
             oa, ra, da, _, _ = ea.step(at)
             ob, rb, db, _, _ = eb.step(at)
-            assert torch.equal(oa, ob) and torch.equal(da, db), (desc, "autoreset obs/done", fx, t)
+            assert torch.equal(oa, ob) and torch.equal(da, db), (desc, "autoreset obs/done", mode, fx, t)
             assert torch.allclose(ra, rb, rtol=0, atol=1e-6), (desc, "autoreset reward", fx, t)
         sa, sb = ea.state(), eb.state()
         for k in sa:
