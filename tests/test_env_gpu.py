@@ -1780,3 +1780,32 @@ def test_randomised_parity_sweep(dev):
         assert w <= REWARD_TOL and wp <= REWARD_TOL
         kernels.add(k)
     assert "k_rollout_mfma" in kernels
+
+
+def test_bench_json_contract_on_the_gpu(dev):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's invocation, here without the extras and the CPU
+    baseline leg): one JSON line with the contract's keys, the roofline object and physically possible numbers."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["num_envs_total"]
+    assert n == 1048576 and abs(d["value"] - n * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
+    assert 1e10 < d["value"] < 6e10  # 10-60 G env-steps/s: above the north-star target, below what 149 B per env-step allow
+    assert d["status_bits"] == 0
