@@ -696,6 +696,12 @@ def main():
         kernel_us = sum(a.elapsed_time(b) for a, b in segs) * 1e3 / (len(segs) * (T - 1))
         kernel_timing = (f"HIP events on the launch stream around the {T - 1} back-to-back step launches of each of the "
                          f"{len(segs)} whole episodes inside the timed region (reset kernels and collectives excluded)")
+    elif graph is None and args.steps < T - 1 and (stepno - args.steps) // T == (stepno - 1) // T and (stepno % T) != 0:
+        # a timed region shorter than an episode that did not cross an episode boundary (the driver's --steps 20): its
+        # launches are nothing but step kernels, so the HIP events around the region itself are the measurement
+        kernel_us = dev_ms * 1e3 / args.steps
+        kernel_timing = (f"HIP events on the launch stream around the {args.steps} back-to-back step launches of the timed "
+                         "region itself (no reset kernel, no collective inside)")
     elif graph is None:
         k_steps = min(T - 2, 140)
         if env._host_auto and T - env._steps_in_episode <= k_steps:
