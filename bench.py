@@ -662,6 +662,10 @@ def main():
     for _ in range(2):
         _w0, _w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         _w0.record(); _w1.record(); _w1.synchronize(); _w0.elapsed_time(_w1)
+    import gc
+
+    gc.collect()
+    gc.disable()  # no collector pause inside the timed region (re-enabled right after it)
     wdist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -684,6 +688,7 @@ def main():
     torch.cuda.synchronize()
     wdist.barrier()
     wall = time.perf_counter() - t0
+    gc.enable()
     wall = wdist.max_over_ranks(wall, device)
     dev_ms = ev0.elapsed_time(ev1)
     status = env.check_status()
