@@ -390,7 +390,10 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
             fn()
         except Exception as e:  # noqa: BLE001
             out[key] = {"error": repr(e)}
-            torch.cuda.synchronize()
+            try:  # after a device-side error the synchronisation raises again: it must not leave this handler,
+                torch.cuda.synchronize()  # or the headline line the wrapper exists to protect would be lost
+            except Exception as e2:  # noqa: BLE001
+                out[key]["sync_error"] = repr(e2)
 
     def always_alert():
         # policy-pessimistic case: every env alerts every day with budget 153, so both coefficient rows are fetched on

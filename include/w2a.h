@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 15
+#define W2A_ABI_VERSION 16
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -314,7 +314,9 @@ int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
  * the step state is current. */
 enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3,
        W2A_Q_LAST_ROLLOUT_KERNEL = 4 /* what the last w2a_rollout launched: -1 none yet, 0 k_rollout (4 lanes per env),
-                                        1 k_rollout64 (lane = env), 2 k_rollout_mfma (int8 matrix cores) */ };
+                                        1 k_rollout64 (lane = env), 2 k_rollout_mfma (int8 matrix cores) */,
+       W2A_Q_LAST_STEP_KERNEL = 5    /* what the last w2a_step launched: -1 none yet, 0 k_step (4 lanes per env),
+                                        1 k_step64 on the canonical state words, 2 k_step64 on the lock-step mirror */ };
 int w2a_query(w2a_env *env, int what);
 
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 15
+    assert lib.w2a_abi_version() == _ffi.ABI_VERSION == 16
     assert lib.w2a_state_bytes(0) == 0
     n = 1000
     b = lib.w2a_state_bytes(n)
@@ -68,9 +68,9 @@ def test_header_enums_match_binding():
                       ("W2A_STEP_UNPACKED", _ffi.STEP_UNPACKED), ("W2A_STEP_NEXT_STEP", _ffi.STEP_NEXT_STEP), ("W2A_PM_VECTOR", 0), ("W2A_PM_MATRIX_F64", 1),
                       ("W2A_PM_MATRIX_I8", 2), ("W2A_Q_LOCKSTEP_DAY", _ffi.Q_LOCKSTEP_DAY),
                       ("W2A_Q_PACKED_ELIGIBLE", _ffi.Q_PACKED_ELIGIBLE), ("W2A_Q_PACKED_CURRENT", _ffi.Q_PACKED_CURRENT),
-                      ("W2A_Q_CANONICAL_CURRENT", _ffi.Q_CANONICAL_CURRENT), ("W2A_Q_LAST_ROLLOUT_KERNEL", _ffi.Q_LAST_ROLLOUT_KERNEL), ("W2A_ABI_VERSION", _ffi.ABI_VERSION)):
+                      ("W2A_Q_CANONICAL_CURRENT", _ffi.Q_CANONICAL_CURRENT), ("W2A_Q_LAST_ROLLOUT_KERNEL", _ffi.Q_LAST_ROLLOUT_KERNEL), ("W2A_Q_LAST_STEP_KERNEL", _ffi.Q_LAST_STEP_KERNEL), ("W2A_ABI_VERSION", _ffi.ABI_VERSION)):
         assert enum(name) == val, name
-    assert enum("W2A_ABI_VERSION") == 15
+    assert enum("W2A_ABI_VERSION") == 16
 
 
 def test_ffi_struct_layout_matches_header():

@@ -22,7 +22,7 @@ p.add_argument("--workload", default="configs2")
 p.add_argument("--steps", type=int, default=24)
 p.add_argument("--num-envs", type=int, default=None)
 p.add_argument("--no-obs", action="store_true")
-p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide"])
+p.add_argument("--step-kernel", default="auto", choices=["auto", "classic", "wide", "unpacked"])
 p.add_argument("--episode-order", default="iid", choices=["iid", "sorted"])
 p.add_argument("--reward-mode", default="sampled", choices=["sampled", "posterior_mean"])
 p.add_argument("--pm-kernel", default="vector", choices=["vector", "matrix", "matrix_i8"],

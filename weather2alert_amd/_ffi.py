@@ -13,7 +13,7 @@ ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE = 1, 2, 4
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED, STEP_UNPACKED, STEP_NEXT_STEP = 1, 2, 8, 16, 32, 64, 128, 256
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 15
+ABI_VERSION = 16
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -24,7 +24,7 @@ SYMBOLS = [
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
     "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward", "w2a_set_posterior_kernel", "w2a_invalidate", "w2a_query", "w2a_set_budget_bound", "w2a_rollout_mfma_workspace_bytes", "w2a_rollout_mfma_prepare",
 ]
-Q_LOCKSTEP_DAY, Q_PACKED_ELIGIBLE, Q_PACKED_CURRENT, Q_CANONICAL_CURRENT, Q_LAST_ROLLOUT_KERNEL = 0, 1, 2, 3, 4
+Q_LOCKSTEP_DAY, Q_PACKED_ELIGIBLE, Q_PACKED_CURRENT, Q_CANONICAL_CURRENT, Q_LAST_ROLLOUT_KERNEL, Q_LAST_STEP_KERNEL = 0, 1, 2, 3, 4, 5
 PM_KERNELS = {"vector": 0, "matrix": 1, "matrix_i8": 2}  # W2A_PM_VECTOR, W2A_PM_MATRIX_F64, W2A_PM_MATRIX_I8
 POLICY_KINDS = {"never": 0, "always": 1, "bernoulli": 2, "threshold": 3, "table": 4}
 

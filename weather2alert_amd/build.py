@@ -25,13 +25,41 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (need the ROCm toolchain to build libw2a.so)")
 
 
+HASH_FILE = LIB + ".srchash"  # sidecar written by build_lib(): what the library was built from
+
+
+def _dep_files() -> list:
+    csrc = os.path.dirname(SRC)
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hip.h", ".h"))) + \
+        [os.path.join(INC, "w2a.h")]
+
+
+def build_hash() -> str:
+    """sha256 over every source the library is compiled from (names + contents) and the extra compiler flags."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in _dep_files():
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(os.environ.get("W2A_CXXFLAGS", "").encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    """The library is missing, or was built from other sources than the ones in the tree. Decided by content hash (the
+    sidecar build_lib() writes), not by file times: a fresh checkout, a copy or a read-only install whose sources merely
+    LOOK newer than a correct prebuilt library must load it as it is. A library without a sidecar (built by hand) falls
+    back to the file-time comparison."""
     if not os.path.exists(LIB):
         return True
+    if os.path.exists(HASH_FILE):
+        try:
+            return open(HASH_FILE).read().strip() != build_hash()
+        except OSError:
+            return True
     m = os.path.getmtime(LIB)
-    csrc = os.path.dirname(SRC)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hip.h"))] + [os.path.join(INC, "w2a.h")]
-    return any(os.path.getmtime(d) > m for d in deps)
+    return any(os.path.getmtime(d) > m for d in _dep_files())
 
 
 STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_step_dispatch.hip.h")
@@ -67,6 +95,10 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(r.stderr)
     os.replace(tmp, LIB)
+    htmp = f"{HASH_FILE}.{os.getpid()}.tmp"
+    with open(htmp, "w") as f:
+        f.write(build_hash() + "\n")
+    os.replace(htmp, HASH_FILE)
     return LIB
 
 

@@ -192,6 +192,7 @@ struct w2a_env {
   const float *rm_xs;
   int rm_valid;                  // the tile list belongs to the current episode's visiting order
   int last_rollout_kernel;       // W2A_Q_LAST_ROLLOUT_KERNEL
+  int last_step_kernel;          // W2A_Q_LAST_STEP_KERNEL
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   int perm_valid;
   // which form of the per-env step state is current (see StateArrays): the canonical arrays, the lock-step mirror,

@@ -226,7 +226,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->perm_valid = 0;
   h->pm_kernel = W2A_PM_VECTOR;
   h->xmax_ws = nullptr;
-  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0; h->last_rollout_kernel = -1;
+  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0; h->last_rollout_kernel = -1; h->last_step_kernel = -1;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -768,6 +768,7 @@ int w2a_query(w2a_env *env, int what) {
     case W2A_Q_PACKED_CURRENT: return env->pk_valid;
     case W2A_Q_CANONICAL_CURRENT: return env->canon_valid;
     case W2A_Q_LAST_ROLLOUT_KERNEL: return env->last_rollout_kernel;
+    case W2A_Q_LAST_STEP_KERNEL: return env->last_step_kernel;
     default: return fail(W2A_ERR_ARG, "w2a_query: unknown item");
   }
 }

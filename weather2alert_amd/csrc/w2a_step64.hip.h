@@ -93,6 +93,10 @@ __device__ __forceinline__ void st16_sc1(void *p, v4f v) {
 __device__ __forceinline__ void st12_sc1(void *p, v3u v) {
   asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st8_sc1(void *p, v2u v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void st4_sc1(void *p, uint32_t v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
@@ -321,8 +325,10 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   h2.b = pack_d1(hist2, ndays, done ? 1u : 0u);
   h2.c = __float_as_uint(ret);
 #if W2A_S64_SC1 & 2
-  st12_sc1(&a.st.hot3[e], v3u{h2.a, h2.b, h2.c});
-  st4_sc1(&a.reward[e], __float_as_uint(r));
+  // the packed variant's state word goes to the lock-step mirror here too (the host marks the mirror current)
+  if (PACKED) st8_sc1(&a.st.pk_hot[e], v2u{pk_pack_hot(used2, streak2, hist2, done ? 1u : 0u), h2.c});
+  else st12_sc1(&a.st.hot3[e], v3u{h2.a, h2.b, h2.c});
+  if (!REWARD_GIVEN) st4_sc1(&a.reward[e], __float_as_uint(r));
   st1_sc1(&a.done[e], done ? 1u : 0u);
 #else
   if (PACKED) a.st.pk_hot[e] = make_uint2(pk_pack_hot(used2, streak2, hist2, done ? 1u : 0u), h2.c);

@@ -78,6 +78,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
       } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
       HIP_TRY(hipGetLastError());
+      env->last_step_kernel = 2;
       env->canon_valid = 0;
       env->pk_t = uni_next >= 0 ? uni_next : env->uni_t;  // the terminal step leaves t where it is (env.py:256-259)
       env->uni_t = uni_next;
@@ -105,6 +106,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
       else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
     }
     HIP_TRY(hipGetLastError());
+    env->last_step_kernel = 1;
     return W2A_OK;
   }
 #endif
@@ -118,6 +120,7 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   else { if (no_obs) W2A_LAUNCH(false, false); else W2A_LAUNCH(false, true); }
 #undef W2A_LAUNCH
   HIP_TRY(hipGetLastError());
+  env->last_step_kernel = 0;
   return W2A_OK;
 }
 

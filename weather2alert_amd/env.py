@@ -105,11 +105,14 @@ class HeatAlertVecEnv(_VectorEnvBase):
     pm_kernel            which kernel computes that contraction: "vector" (fp64 FMAs on the vector ALU with
                          DPP-broadcast coefficients), "matrix" (fp64 matrix cores, v_mfma_f64_16x16x4_f64),
                          "matrix_i8" (int8 matrix cores on exact fixed-point digits of both operands,
-                         v_mfma_i32_16x16x64_i8 with int32 accumulation; csrc/w2a_posterior_i8.hip.h), or "auto"
-                         (default): all are timed once on this env's own batch after the first reset and the fastest
-                         one is kept (``pm_kernel_choice`` / ``pm_kernel_timing_us`` say which and why). The kernels
-                         agree to ~1e-7, not to the last bit: name one for run-to-run bit reproducibility (a
-                         checkpoint carries the choice, so a resumed run continues on the same kernel).
+                         v_mfma_i32_16x16x64_i8 with int32 accumulation; csrc/w2a_posterior_i8.hip.h; the DEFAULT: the
+                         fastest of the three on MI355X, and a fixed choice keeps rewards bit-reproducible from run
+                         to run and from rank to rank), or "auto" (opt-in): all are timed once on this env's own batch
+                         after the first reset and the fastest one is kept (``pm_kernel_choice`` /
+                         ``pm_kernel_timing_us`` say which and why). The kernels agree to ~1e-7, not to the last bit,
+                         so "auto" gives up bit reproducibility between runs; within one torch.distributed job rank
+                         0's choice is broadcast, so every shard computes with the same kernel, and a checkpoint
+                         carries the choice, so a resumed run continues on it.
     step_kernel          "auto" (default): batches of >= 131 072 envs with faithful semantics run the 64-envs-per-wave
                          kernel (csrc/w2a_step64.hip.h; in-kernel autoreset included), everything else the
                          4-lanes-per-env kernel (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
@@ -150,7 +153,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         step_kernel: Literal["auto", "classic", "wide", "unpacked"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         rollout_order: bool = True,
-        pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "auto",
+        pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "matrix_i8",
         rollout_mfma: bool = True,
     ):
         self._lib = _ffi.load()
@@ -338,9 +341,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
     @property
     def step_kernel_name(self) -> str:
         """The step kernel w2a_step launches for this env right now (mirrors the dispatch in csrc/w2a_kernels.hip)."""
-        wide = self._pm or self.step_kernel == "wide" or (self.step_kernel == "auto" and
+        wide = self._pm or self.step_kernel == "wide" or (self.step_kernel in ("auto", "unpacked") and
                                                           self.num_envs >= _ffi.S64_MIN_ENVS)
         return "k_step64" if (wide and self.step_kernel != "classic") else "k_step"
+
+    @property
+    def last_step_kernel(self) -> str | None:
+        """Which kernel the last step() launched, from the library's own record: "k_step" (4 lanes per env), "k_step64"
+        (64 envs per wave, canonical state words), "k_step64<packed>" (the lock-step mirror) or None before the first."""
+        return {0: "k_step", 1: "k_step64", 2: "k_step64<packed>"}.get(
+            self._lib.w2a_query(self._h, _ffi.Q_LAST_STEP_KERNEL))
 
     @property
     def packed_state(self) -> bool:
@@ -651,6 +661,15 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 best[name] = min(times[1:])
             self.pm_kernel_timing_us = best
             self.pm_kernel_choice = min(best, key=best.get)
+            # one decision per job: the kernels differ in the last bits, and the device RNG's shard invariance (env_gid0)
+            # would be worth little if the same global env id got other reward bits on another rank
+            import torch.distributed as td
+
+            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+                names = list(_ffi.PM_KERNELS)
+                pick = torch.tensor([names.index(self.pm_kernel_choice)], dtype=torch.int32, device=self.device)
+                td.broadcast(pick, src=0)
+                self.pm_kernel_choice = names[int(pick.item())]
             _ffi.check(self._lib.w2a_set_posterior_kernel(self._h, _ffi.PM_KERNELS[self.pm_kernel_choice]),
                        "w2a_set_posterior_kernel")
             self.check_status()  # zero actions on a fresh episode raise no status bit; clear what a mid-episode call may
@@ -910,19 +929,30 @@ class HeatAlertVecEnv(_VectorEnvBase):
                   "average_streak", "stdev_streak", "alerts")  # callbacks.py:136-146
 
     @staticmethod
-    def episode_rows(out: dict) -> list[dict]:
+    def episode_rows(out: dict, chunk: int = 65536) -> list[dict]:
         """One row per env in the format of the reference's FinalEvalCallback (callbacks.py:116-146) from whole-episode
         rollout outputs: year, alert_budget, sum_alerts and reward as read when env.t == n_days - 2 (:128-132), alert
         day / streak statistics over the GRANTED alerts of the whole episode (:118-126), and the granted-alert list.
         Every statistic is computed on the device from the day bitmaps (the same run-length formulation as
-        callback_stats, per env instead of pooled); the host only formats the rows."""
+        callback_stats, per env instead of pooled); the host only formats the rows. The envs are processed `chunk` at a
+        time: the [chunk, T] intermediates stay at ~100 MB however large the batch is."""
+        n = out["alert_days"].shape[0]
+        rows: list[dict] = []
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            rows.extend(HeatAlertVecEnv._episode_rows_chunk({k: out[k][lo:hi] for k in (
+                "alert_days", "n_days", "year", "budget", "return_snapshot")}))
+        return rows
+
+    @staticmethod
+    def _episode_rows_chunk(out: dict) -> list[dict]:
         act = out["alert_days"]
         n, T = act.shape
         dev = act.device
         nd = out["n_days"].long()
         day = torch.arange(T, device=dev)
         live = day[None, :] < nd[:, None]
-        a = (act & live).to(torch.int64)
+        a = (act & live).to(torch.int32)  # counts <= T <= 1023: exact in int32 and in float64 below
         cnt = a.sum(1)
         # day of each granted alert as the callback sees it: env.t after the step = min(day + 1, n_days - 1)
         t_after = torch.minimum(day[None, :] + 1, nd[:, None] - 1).double()
@@ -930,16 +960,19 @@ class HeatAlertVecEnv(_VectorEnvBase):
         c = cnt.clamp(min=1).double()
         mean_t = (t_after * af).sum(1) / c
         std_t = (((t_after - mean_t[:, None]) ** 2) * af).sum(1).div(c).sqrt()
+        del t_after, af
         # streaks of granted alerts ended by a no-alert day inside the episode: run length at the day before
-        cs = a.cumsum(1)
+        cs = a.cumsum(1, dtype=torch.int32)
         zero_c = torch.where(a == 0, cs, torch.zeros_like(cs)).cummax(1).values
         run = (cs - zero_c)[:, :-1].double()
         ended = ((a[:, 1:] == 0) & (a[:, :-1] == 1) & live[:, 1:]).double()
+        del cs, zero_c
         ns = ended.sum(1)
         cn = ns.clamp(min=1.0)
         mean_s = (run * ended).sum(1) / cn
         std_s = (((run - mean_s[:, None]) ** 2) * ended).sum(1).div(cn).sqrt()
-        seen = (day[None, :] < (nd[:, None] - 2)).to(torch.int64)
+        del run, ended
+        seen = (day[None, :] < (nd[:, None] - 2)).to(torch.int32)
         sum_alerts = (a * seen).sum(1)
         h = {k: v.cpu().numpy() for k, v in dict(
             act=a.to(torch.uint8), nd=nd, year=out["year"], bud=out["budget"], snap=out["return_snapshot"], cnt=cnt,
