@@ -17,6 +17,10 @@ from weather2alert_amd import synth, tables
 pytestmark = pytest.mark.gpu
 
 REWARD_TOL = 1e-5  # stated by north_star
+# returns summed over up to 153 days in f32 inside a kernel against the float64 oracle: the north star's 1e-5 is a per-step
+# reward bound; a sum of n rewards may differ by n x 1e-5 at most (1.5e-3 per episode). Measured: <= 5.3e-7 relative
+# (returns of magnitude 10^2..10^3), so the suite holds the kernels to 2e-6 relative + 2e-5 absolute
+RETURN_RTOL, RETURN_ATOL = 2e-6, 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -837,7 +841,7 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
     np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
     np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
-    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     assert not out["done"].any()
     # --- 10 days by step() with explicit actions, state stays consistent
     for _ in range(10):
@@ -851,7 +855,7 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
     np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
     np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
-    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     assert out["done"].all()
     s2 = {k: v.cpu().numpy() for k, v in env.state().items()}
     np.testing.assert_array_equal(s2["used"], V.used)
@@ -862,6 +866,52 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     np.testing.assert_array_equal(stats["alert_day_hist"].numpy(), days_o.sum(0))
     assert env.check_status() == 0
     env.close()
+
+
+@pytest.mark.parametrize("kernel", ["k_rollout_mfma", "k_rollout64", "k_rollout"])
+def test_rollout_kernels_per_day_rewards(dev, kernel):
+    """Every DAY of every rollout kernel against the oracle (a whole-episode return could hide compensating errors):
+    one-day rollouts (n_steps=1; `return` is then that day's reward) through a whole episode, each day's reward within
+    the per-step bar 1e-5 of the float64 oracle and of step() on a twin batch fed the actions the policy attempted; the
+    integer state of the two batches stays identical, and so does the running return up to f32 rounding."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=5, n_days=61, seed=23, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n, gid0 = 777, 4242
+    kw = dict(tables=ct, device=dev, autoreset="disabled", env_gid0=gid0, similar_climate_counties=True)
+    A = HeatAlertVecEnv(n, rollout_order=kernel != "k_rollout", rollout_mfma=kernel == "k_rollout_mfma", **kw)
+    B = HeatAlertVecEnv(n, **kw)
+    A.reset(seed=77, options={"budget": 5})
+    B.reset(seed=77, options={"budget": 5})
+    st = _oracle_for_env(A, V)
+    pol = dict(kind="bernoulli", p=0.3, seed=5)
+    worst = worst_step = 0.0
+    for t in range(ct.T):
+        out = A.rollout(pol, n_steps=1, alert_mask=True)
+        assert A.last_rollout_kernel == kernel, (t, A.last_rollout_kernel)
+        att = out["attempt_days"][:, t].to(torch.int32)
+        u = O.devrng_policy_uniform_vec(5, gid0 + np.arange(n), st["episode_no"], np.full(n, t))
+        np.testing.assert_array_equal(att.cpu().numpy(), (u < np.float32(0.3)).astype(np.int32))
+        _, r_b, done_b, _, _ = B.step(att)
+        _, r_o, done_o, actual_o = V.step(att.cpu().numpy())
+        r_a = out["return"].cpu().numpy().astype(np.float64)
+        worst = max(worst, float(np.abs(r_a - r_o).max()))
+        worst_step = max(worst_step, float(np.abs(r_a - r_b.cpu().numpy()).max()))
+        np.testing.assert_array_equal(out["alerts"].cpu().numpy(), actual_o)
+        np.testing.assert_array_equal(out["done"].cpu().numpy(), done_o)
+    assert worst <= REWARD_TOL and worst_step <= 2e-6, (worst, worst_step)
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        if k == "episode_return":
+            torch.testing.assert_close(sa[k], sb[k], rtol=RETURN_RTOL, atol=RETURN_ATOL)
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+    assert A.check_status() == 0 and B.check_status() == 0
+    print(f"{kernel}: per-day |reward - oracle| <= {worst:.2e}, vs step() <= {worst_step:.2e}")
+    A.close()
+    B.close()
 
 
 def test_rollout_visiting_order_does_not_change_results(dev):
@@ -939,7 +989,7 @@ def test_matrix_core_rollout_matches_vector_rollout_and_oracle(dev, kind):
         np.testing.assert_array_equal(oa["attempts_over_budget"].cpu().numpy(), ov_o)
         np.testing.assert_array_equal(oa["alert_days"].cpu().numpy(), days_o)
         torch.testing.assert_close(oa["return"], ob["return"], rtol=3e-6, atol=3e-5)
-        np.testing.assert_allclose(oa["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(oa["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
         return oa
 
     check(21)   # starts on day 0, ends inside a 16-day chunk
@@ -1081,7 +1131,7 @@ def test_rollout_with_corrected_semantics_flags(dev, order):
     np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
     np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
     np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
-    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     assert out["done"].all() and env.check_status() == 0
     env.close()
 
@@ -1401,7 +1451,7 @@ def test_posterior_mean_reward_matches_oracle(dev, n, n_fips, n_samples, augment
     s1, s2 = pm.state(), sm.state()
     for k in ("t", "used", "streak", "hist14", "last_actual", "at_budget", "finished"):
         assert torch.equal(s1[k], s2[k]), k
-    np.testing.assert_allclose(s1["episode_return"].cpu().numpy(), ret, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(s1["episode_return"].cpu().numpy(), ret, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     assert pm.check_status() == 0
     print(f"posterior mean [{pm_kernel}] n={n} S={ct.S} draws={n_samples}: max |reward - oracle| = {worst:.3e}")
     pm.close()
@@ -1447,7 +1497,7 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_ke
         np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
         np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
         np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
-        np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
         return ret_o
 
     r1 = check(env.rollout(pol, n_steps=40, alert_mask=True), 40)
@@ -1461,7 +1511,7 @@ def test_posterior_mean_rollout_matches_policy_loop(dev, kind, one_launch, pm_ke
     out = env.rollout(pol, alert_mask=True)
     r3 = check(out, ct.T)
     assert out["done"].all() and (out["first_day"] == 45).all()
-    np.testing.assert_allclose(out["final_return"].cpu().numpy(), r1 + r2 + r3, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(out["final_return"].cpu().numpy(), r1 + r2 + r3, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     # the batch was reset after its terminal day (lock step, same_step): the next call evaluates the next episode
     assert (env.state()["episode_no"] == 1).all() and (env.state()["t"] == 0).all()
     st = _oracle_for_env(env, V)
@@ -1502,7 +1552,7 @@ def test_posterior_mean_rollout_many_effectiveness_rows_and_full_tiles(dev, one_
     np.testing.assert_array_equal(out["alerts"].cpu().numpy(), al_o)
     np.testing.assert_array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o)
     np.testing.assert_array_equal(out["alert_days"].cpu().numpy(), days_o)
-    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     assert env.check_status() == 0
     env.close()
 
@@ -1556,11 +1606,11 @@ def test_posterior_mean_rollout_after_a_masked_reset(dev, one_launch, pm_kernel)
     np.testing.assert_array_equal(g["attempts_over_budget"][idxB], ovB)
     np.testing.assert_array_equal(g["alert_days"][idxA], dA[idxA])
     np.testing.assert_array_equal(g["alert_days"][idxB], dB)
-    np.testing.assert_allclose(g["return"][idxA], rA[idxA], rtol=2e-5, atol=1e-3)
-    np.testing.assert_allclose(g["return"][idxB], rB, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g["return"][idxA], rA[idxA], rtol=RETURN_RTOL, atol=RETURN_ATOL)
+    np.testing.assert_allclose(g["return"][idxB], rB, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     # the finished half's return was not touched again while the other half ran on
-    np.testing.assert_allclose(g["final_return"][idxA], (retA + rA)[idxA], rtol=2e-5, atol=1e-3)
-    np.testing.assert_allclose(g["final_return"][idxB], rB, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g["final_return"][idxA], (retA + rA)[idxA], rtol=RETURN_RTOL, atol=RETURN_ATOL)
+    np.testing.assert_allclose(g["final_return"][idxB], rB, rtol=RETURN_RTOL, atol=RETURN_ATOL)
     s2 = {k: v.cpu().numpy() for k, v in env.state().items()}
     assert (s2["finished"] == 1).all() and (s2["t"] == s2["n_days"] - 1).all()
     env.close()
@@ -1762,11 +1812,12 @@ def test_rccl_single_rank_return_gather(dev):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_randomised_parity_sweep(dev):
-    """tools/stress_parity.py, 16 seeded cases: random table shapes (S, Y, T, draws), batch sizes around the tile
+    """tools/stress_parity.py, 300 seeded cases: random table shapes (S, Y, T, draws), batch sizes around the tile
     boundaries (1, 63, 64, 65, 255 ... 4097), budgets, action rates and policies through every step-kernel form, both
-    sampled-reward rollout kernels and the posterior-mean kernels, each against the oracle (the 640-case run is
-    profiles/r03/stress_parity.log)."""
+    sampled-reward rollout kernels and the posterior-mean kernels, each against the oracle (longer runs of the same
+    tool: profiles/r03/stress_parity.log, profiles/r04/)."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(__file__), "..", "tools",
@@ -1775,7 +1826,7 @@ def test_randomised_parity_sweep(dev):
     spec.loader.exec_module(sp)
     rng = np.random.default_rng(2024)
     kernels = set()
-    for i in range(16):
+    for i in range(300):
         w, wp, k = sp.run_case(i, rng, dev)
         assert w <= REWARD_TOL and wp <= REWARD_TOL
         kernels.add(k)

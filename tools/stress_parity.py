@@ -7,7 +7,7 @@ against 4-lanes-per-env kernel (oracle/heatalert_oracle.py; test infrastructure,
 
     python tools/stress_parity.py [--cases 40] [--seed 0]
 
-Bars: integers / observations / done exact, reward <= 1e-5, rollout returns <= 2e-5 relative. Prints one line per case
+Bars: integers / observations / done exact, reward <= 1e-5, rollout returns <= 2e-6 relative + 2e-5 absolute. Prints one line per case
 and a summary; exits non-zero on the first violation (with the case's parameters, so that it can be replayed)."""
 import argparse
 import os
@@ -24,6 +24,10 @@ from oracle import heatalert_oracle as O  # noqa: E402
 from weather2alert_amd import HeatAlertVecEnv, synth, tables  # noqa: E402
 
 EDGE_N = [1, 2, 15, 16, 17, 63, 64, 65, 127, 255, 256, 257, 1023, 1025, 4097]
+# returns summed over up to 153 days in f32 inside a kernel against the float64 oracle: the north star's 1e-5 is a per-step
+# reward bound; a sum of n rewards may differ by n x 1e-5 at most (1.5e-3 per episode). Measured: <= 5.3e-7 relative
+# (returns of magnitude 10^2..10^3), so the suite holds the kernels to 2e-6 relative + 2e-5 absolute
+RETURN_RTOL, RETURN_ATOL = 2e-6, 2e-5
 
 
 def oracle_for(env, V):
@@ -101,7 +105,7 @@ def run_case(i, rng, dev):
             assert np.array_equal(out["alerts"].cpu().numpy(), al_o), tag + ("alerts",)
             assert np.array_equal(out["attempts_over_budget"].cpu().numpy(), ov_o), tag + ("over",)
             assert np.array_equal(out["alert_days"].cpu().numpy(), days_o), tag + ("days",)
-            np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3, err_msg=str(tag))
+            np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL, err_msg=str(tag))
             assert bool(out["done"].all()), tag + ("done",)
     env.close()
     # ---- a fresh lock-step batch through the matrix-core rollout (the restored one above has lost lock-step knowledge)
@@ -121,7 +125,7 @@ def run_case(i, rng, dev):
     tag = (desc, kindp, used_mfma, "fresh")
     assert np.array_equal(out["alerts"].cpu().numpy(), al_o), tag + ("alerts",)
     assert np.array_equal(out["alert_days"].cpu().numpy(), days_o), tag + ("days",)
-    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=2e-5, atol=1e-3, err_msg=str(tag))
+    np.testing.assert_allclose(out["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL, err_msg=str(tag))
     assert e3.check_status() == 0, tag
     e3.close()
     # ---- posterior-mean reward, one of the three kernels, a few days
