@@ -184,8 +184,9 @@ class HandleModel:
     def _note_cfg(self, cfg):
         self._note_budgets(cfg[3] if cfg[3] >= 0 else self.b0_max, cfg[4], cfg[5])
 
-    def _device_reset(self, sel, restart):
-        """w2a_reset_device_rng on the selected envs with self.reset_cfg (+ the relabelling sort in sorted mode)."""
+    def _device_reset(self, sel, restart, masked=False):
+        """w2a_reset_device_rng on the selected envs with self.reset_cfg (+ the relabelling sort in sorted mode).
+        masked: a mask was PASSED (whatever it selects: the handle cannot see its contents)."""
         idx = np.nonzero(sel)[0]
         ep = np.zeros(len(idx), np.int64) if restart else self.episode_no[idx] + 1
         cw, yi, cc, sm, b, so = draw_episodes(self.ct, self.reset_cfg, self.gid0 + idx, ep, self.sticky[idx],
@@ -194,7 +195,7 @@ class HandleModel:
         self.sticky[idx] = so
         self._assign(idx, cw, yi, cc, sm, b)
         self._note_cfg(self.reset_cfg)
-        self._note_launch_reset(masked=not sel.all())
+        self._note_launch_reset(masked=masked)
         if self.episode_order == "sorted":
             assert sel.all()
             self._relabel()
@@ -240,7 +241,7 @@ class HandleModel:
         if self.lockstep and mask is not None:
             self._leave_lockstep()
         self.reset_cfg = self.device_cfg(seed, options)
-        self._device_reset(sel, restart=True)
+        self._device_reset(sel, restart=True, masked=mask is not None)
         self._note_cfg(self.reset_cfg)  # w2a_set_autoreset after the reset
         self.was_reset = True
 
@@ -288,8 +289,10 @@ class HandleModel:
 
     def step(self, actions, dev_reward=None) -> dict:
         """env.step(actions). dev_reward: the f32 rewards the device returned for this call (each compared with the
-        expected one by the caller): the handle adds exactly those into its f32 episode return, so with them the model
-        tracks the return bit for bit; without them (graph replays) a tolerance accumulates instead."""
+        expected one by the caller): the handle adds those into its f32 episode return, so with them the model tracks
+        the return to the last ulp or two (the compiler contracts `ret + c * base * (1 - eff)` into an FMA, so the
+        kernel's sum is not always the sum of the ROUNDED reward it stored: 2 ulp of slack per step); without them
+        (graph replays) the per-step reward tolerance accumulates instead."""
         n, V = self.n, self.V
         a = np.asarray(actions).astype(np.int64).copy()
         if self.pending_reset:  # host-driven next_step: this call restarts the whole batch, nothing is stepped
@@ -314,13 +317,17 @@ class HandleModel:
         r = np.where(stepped, r, 0.0)
         add = np.asarray(dev_reward, np.float32) if dev_reward is not None else r.astype(np.float32)
         self.ret32 = np.where(stepped, (self.ret32 + add).astype(np.float32), self.ret32)
-        if dev_reward is None:
-            self.ret_tol = self.ret_tol + np.where(stepped, 1e-5 + 2e-6 * np.abs(self.ret32), 0.0)
+        per_step = (1e-5 + 2e-6 * np.abs(self.ret32)) if dev_reward is None else 2.4e-7 * np.maximum(np.abs(self.ret32), 1.0)
+        self.ret_tol = self.ret_tol + np.where(stepped, per_step, 0.0)
         self.final_return = np.where(done, self.ret32, self.final_return)
         self.final_tol = np.where(done, self.ret_tol, self.final_tol)
         self.finished = np.where(stepped, done, self.finished)
         if self.write_obs:
-            self.obs = V.obs.astype(np.float32)
+            # the caller's buffer: a stepped env's row is written unless its terminal step has just run (the stale row
+            # stays, Q6; W2A_FIX_OBS writes the last row) -- what "stale" is depends on the buffer, e.g. rollouts advance
+            # days without writing rows
+            written = stepped & (~done | ("obs" in self.fixes))
+            self.obs[written] = V.obs[written].astype(np.float32)
         self._note_step(mode in ("dev_same", "dev_next"))
         rs = done if mode == "dev_same" else (restart_in if mode == "dev_next" else np.zeros(n, bool))
         if rs.any():

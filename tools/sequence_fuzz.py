@@ -63,7 +63,10 @@ def draw_config(rng):
     n_days = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 24, 40, 153], p=[.08, .1, .12, .14, .14, .14, .1, .08, .06, .04]))
     ragged = bool(rng.random() < 0.25)
     key = (int(rng.integers(3, 20)), int(rng.integers(1, 4)), int(rng.integers(1, 8)), n_days, ragged, int(rng.integers(0, 6)))
-    n = int(rng.choice(EDGE_N)) if rng.random() < 0.6 else int(rng.integers(1, 400))
+    u = rng.random()
+    n = int(rng.choice(EDGE_N)) if u < 0.6 else int(rng.integers(1, 400)) if u < 0.95 else int(rng.integers(1025, 6000))
+    if u > 0.995 and n_days <= 16:
+        n = 131072 + int(rng.integers(0, 300))  # step_kernel="auto" picks the 64-envs-per-wave kernel by itself from here
     pm = bool(rng.random() < 0.2)
     autoreset = str(rng.choice(["same_step", "next_step", "disabled"], p=[.45, .3, .25]))
     lockstep = None if rng.random() < 0.7 else False
@@ -110,6 +113,11 @@ class Runner:
                              step_kernel=c["step_kernel"], rollout_order=c["rollout_order"], rollout_mfma=c["rollout_mfma"],
                              pm_kernel=c["pm_kernel"])
         self.n = n
+        # even sequences read the full decoded state after EVERY operation (complete comparison, but each read brings
+        # the canonical state words up to date); odd ones only where the sequence itself asks for it (a stale form
+        # then has to show in what later operations compute)
+        self.state_every_op = i % 2 == 0
+        self.log[0] += f"; state after every op: {self.state_every_op}"
         self.ckpt = None
         self.graph_done = False
         self.stats = {"ops": 0, "steps": 0, "resets": 0, "rollouts": 0, "graphs": 0, "ckpt": 0, "worst": 0.0,
@@ -118,7 +126,7 @@ class Runner:
 
     # ------------------------------------------------------------------ checking
     def fail(self, what):
-        raise SequenceFailure("\n".join(self.log[-40:]) + f"\n>>> {what}")
+        raise SequenceFailure("\n".join(self.log[:1] + self.log[1:][-60:]) + f"\n>>> {what}")
 
     def q(self, what):
         return self.env._lib.w2a_query(self.env._h, what)
@@ -344,6 +352,16 @@ class Runner:
         e._regroup()  # posterior_mean: the column grouping was dropped with everything else
         self.m.py_order_stale = True
 
+    def op_switch_kernel(self):
+        """A/B switches a user may flip between calls: the step kernel form and the rollout options."""
+        e, m, rng = self.env, self.m, self.rng
+        sk = str(rng.choice(["auto", "wide", "unpacked"] + ([] if m.pm else ["classic"])))
+        e.step_kernel = m.step_kernel = sk
+        e._set_step_mode()
+        e.rollout_order = m.rollout_order = bool(rng.random() < 0.8)
+        e.rollout_mfma = m.rollout_mfma = bool(rng.random() < 0.8)
+        self.log.append(f"switch: step_kernel={sk}, rollout_order={e.rollout_order}, rollout_mfma={e.rollout_mfma}")
+
     def op_graph(self):
         """A block of K step() calls captured into a hipGraph and replayed R times (autoreset in the kernel or disabled:
         the host must have nothing to do between the steps of a replayed block)."""
@@ -396,7 +414,7 @@ class Runner:
         for _ in range(n_ops):
             partial_ok = not sorted_mode and not pm_auto  # masks / tuples: refused there by the env (by design)
             ops = [("step", 40), ("burst", 6), ("rollout_part", 6), ("rollout_whole", 3), ("reset", 5), ("state", 6),
-                   ("ckpt", 3), ("status", 3), ("invalidate", 2)]
+                   ("ckpt", 3), ("status", 3), ("invalidate", 2), ("switch", 2)]
             if partial_ok:
                 ops += [("reset_masked", 5), ("tuples", 3), ("tuples_masked", 3)]
             if self.ckpt is not None:
@@ -433,6 +451,8 @@ class Runner:
                 self.op_invalidate()
             elif op == "graph":
                 self.op_graph()
+            elif op == "switch":
+                self.op_switch_kernel()
             elif op == "status":
                 self.log.append("check_status()")
                 self.check_status("check_status()", self.expect_status)
@@ -448,6 +468,9 @@ class Runner:
         where = self.log[-1]
         self.check_obs(where)
         self.check_flags(where)
+        if self.state_every_op:
+            self.check_state(where + " [state after the operation]")
+            self.check_flags(where + " [after state()]")
         if self.verbose:
             print("   ", where, flush=True)
 
@@ -460,7 +483,7 @@ def run_sequence(i, master_seed, dev, verbose=False):
     except SequenceFailure:
         raise
     except Exception as e:  # noqa: BLE001  (an exception inside the env is a finding too: show the sequence)
-        raise SequenceFailure("\n".join(r.log[-40:]) + f"\n>>> exception {e!r}") from e
+        raise SequenceFailure("\n".join(r.log[:1] + r.log[1:][-60:]) + f"\n>>> exception {e!r}") from e
     finally:
         try:
             r.env.close()

@@ -83,7 +83,11 @@ __global__ void k_pm_prep(const PosteriorArgs a) {
   const uint32_t rem = (uint32_t)min(max((int32_t)rt.z, 0), 65535);
   const uint32_t pk = (uint32_t)rt.x | ((uint32_t)rt.y << 1) | ((uint32_t)rt.w << 11) | (ga << 15) | (rem << 16);
   a.prep[W2A_PM_PREP_SCATTER ? a.inv[e] : e] = make_uint4(xrow, pk, W_COL(c.c), e);
-  if (d.st_bits) atomicOr(a.status, (int)d.st_bits);
+  // a finished env is no error HERE: in policy loops over batches that are not in lock step the step that follows runs
+  // with W2A_STEP_SKIP_FINISHED and leaves such envs alone; without that flag the step itself raises the bit
+  // (found by tools/sequence_fuzz.py: a whole-episode rollout through the per-day calls left W2A_ST_STEP_AFTER_DONE set)
+  const uint32_t bits = d.st_bits & ~(uint32_t)W2A_ST_STEP_AFTER_DONE;
+  if (bits) atomicOr(a.status, (int)bits);
 }
 
 __global__ void k_group_inverse(const uint32_t *perm, uint32_t *inv, int64_t n) {
