@@ -138,7 +138,10 @@ const char *w2a_last_error(void);
  * whenever an entry point needs the other one; a caller that rewrites the state buffer behind the library's back
  * (checkpoint restore) must call w2a_invalidate. Stream capture: a w2a_step recorded into a hipGraph always uses the
  * canonical form (the packed kernel takes the day as an argument, which a replay would not advance), and the handle
- * keeps to it from then on. */
+ * keeps to it from then on: replays advance days -- and, with W2A_STEP_AUTORESET, re-draw episodes -- behind the
+ * host's back, so such a handle never again claims to know the day (no packed steps, no matrix-core rollout), and after
+ * a recorded autoreset step w2a_group_by_column no longer makes w2a_posterior_mean_reward available.
+ * The decisions are plain C++ in csrc/w2a_bookkeeping.h (run on the CPU under sanitizers by tests/test_bookkeeping_cpu.py). */
 size_t w2a_state_bytes(int64_t num_envs);
 
 /* Replaces HeatAlertEnv.__init__ (env.py:20-105) for `num_envs` envs whose global ids are
@@ -322,10 +325,18 @@ int w2a_query(w2a_env *env, int what);
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived
  * form (lock-step mirror, column grouping, what is known about days and budgets). */
 int w2a_invalidate(w2a_env *env);
-/* The library tracks an upper bound of every env's budget from the reset arguments (the packed lock-step form holds
- * budgets in 16 bits). Budgets handed over in DEVICE memory (w2a_reset with a budget array, a restored checkpoint) are
- * unknown to it and switch the packed form off; a caller that knows their maximum says so here (bound < 0: unknown
- * again). The bound never drops below what earlier resets may have left behind as sticky budgets. */
+/* The library tracks an upper bound of every budget the state buffer holds -- the current episodes' and the sticky
+ * ones later device-RNG resets hand out again (env.py:167-170) -- from the reset arguments (the packed lock-step form
+ * holds budgets in 16 bits). Budgets handed over in DEVICE memory (w2a_reset with a budget array, a restored
+ * checkpoint) are unknown to it and switch the packed form off; a caller that knows their maximum says so here
+ * (bound < 0: unknown again).
+ *   after w2a_reset:      `bound` covers the budgets just handed over; the library combines it with what it knew before
+ *                         (sticky budgets of earlier episodes live on). If that was "no bound exists" -- a sticky
+ *                         W2A_BUDGET_CENTERED budget is a random walk, also inside the kernels -- the statement changes
+ *                         nothing: the unbounded values are still there as sticky budgets.
+ *   after w2a_invalidate: `bound` must cover EVERYTHING the restored buffer holds, sticky budgets included
+ *                         (w2a_state_view.budget and .sticky_budget), and is taken as such.
+ * The parameters of w2a_set_autoreset keep counting on top of either (in-kernel autoresets go on drawing with them). */
 int w2a_set_budget_bound(w2a_env *env, int64_t bound);
 
 /* Synchronise `stream`, read and clear the device status word (host int out). */

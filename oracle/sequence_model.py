@@ -115,7 +115,7 @@ class HandleModel:
         self.was_reset = False
         # ---- mirror of the handle's bookkeeping (csrc/w2a_kernels.hip: w2a_env flags)
         self.known_day = -1
-        self.bound, self.bound_known = 0, 0
+        self.bound, self.bound_known, self.foreign, self.auto_note = 0, 0, False, None
         self.graph_captured = False
         self.packed_current = False
         self.order_set = False
@@ -158,9 +158,12 @@ class HandleModel:
             self.obs[sel] = rows[sel].astype(np.float32)
 
     def _note_budgets(self, cand, mode, sticky):
+        if mode == BUDGET_CENTERED and sticky:  # a sticky random walk: no bound, and none can be restored
+            self.bound = self.bound_known = INF
+            return
         if self.bound != INF:
             self.bound_known = self.bound
-        if cand < 0 or (mode == BUDGET_CENTERED and sticky):
+        if cand < 0:
             self.bound = INF
             return
         if mode == BUDGET_CENTERED:
@@ -172,17 +175,28 @@ class HandleModel:
         if b < 0:
             self.bound = INF
             return
-        prev = self.bound if self.bound != INF else self.bound_known
-        self.bound = max(b, prev)
+        if self.foreign:  # the first statement after w2a_invalidate covers the whole restored buffer
+            self.bound = self.bound_known = b
+            self.foreign = False
+        else:
+            prev = self.bound if self.bound != INF else self.bound_known
+            if prev == INF:
+                return
+            self.bound = max(b, prev)
+        if self.auto_note is not None:  # the handle's autoreset parameters go on handing out their budgets
+            self._note_budgets(*self.auto_note)
 
     def _note_launch_reset(self, masked):
         """launch_reset for from_tuples != 2."""
         self.rm_valid = False
         self.packed_current = False
-        self.known_day = 0 if (not masked and self.uni_nd > 0) else -1
+        self.known_day = 0 if (not masked and self.uni_nd > 0 and not self.graph_captured) else -1
 
-    def _note_cfg(self, cfg):
-        self._note_budgets(cfg[3] if cfg[3] >= 0 else self.b0_max, cfg[4], cfg[5])
+    def _note_cfg(self, cfg, set_autoreset=False):
+        args = (cfg[3] if cfg[3] >= 0 else self.b0_max, cfg[4], cfg[5])
+        if set_autoreset:  # w2a_set_autoreset: remembered by the handle
+            self.auto_note = args
+        self._note_budgets(*args)
 
     def _device_reset(self, sel, restart, masked=False):
         """w2a_reset_device_rng on the selected envs with self.reset_cfg (+ the relabelling sort in sorted mode).
@@ -242,7 +256,7 @@ class HandleModel:
             self._leave_lockstep()
         self.reset_cfg = self.device_cfg(seed, options)
         self._device_reset(sel, restart=True, masked=mask is not None)
-        self._note_cfg(self.reset_cfg)  # w2a_set_autoreset after the reset
+        self._note_cfg(self.reset_cfg, set_autoreset=True)  # w2a_set_autoreset after the reset
         self.was_reset = True
 
     def reset_tuples(self, seed, ep, mask=None, options=None):
@@ -264,7 +278,7 @@ class HandleModel:
         self.py_order_stale = True
         if self.autoreset in ("same_step", "next_step"):
             self.reset_cfg = self.device_cfg(seed, options)
-            self._note_cfg(self.reset_cfg)
+            self._note_cfg(self.reset_cfg, set_autoreset=True)
         self.was_reset = True
 
     # ------------------------------------------------------------------------------------------ step
@@ -422,12 +436,14 @@ class HandleModel:
                     self.rm_valid = True
             self.last_rollout_kernel = 2 if (self.rm_valid and self.order_set and not self.fixbits and
                                              self.known_day >= 0) else (1 if self.order_set else 0)
-            self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd) else -1
+            self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd and
+                                                        not self.graph_captured) else -1
             self.packed_current = False
         else:
             one_launch = self.pm_kernel != "matrix" and steps > 0
             if one_launch:
-                self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd) else -1
+                self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd and
+                                                            not self.graph_captured) else -1
             else:
                 for _ in range(steps):
                     self._note_step(False)
@@ -483,9 +499,8 @@ class HandleModel:
         return d
 
     def note_invalidate(self):
-        if self.bound != INF:
-            self.bound_known = self.bound
-        self.bound = INF
+        self.bound = self.bound_known = INF
+        self.foreign = True
         self.known_day = -1
         self.rm_valid = False
         self.packed_current = False
@@ -504,5 +519,5 @@ class HandleModel:
         self.note_invalidate()
         self.note_set_budget_bound(int(max(int(self.V.budget.max()), int(self.sticky.max()), 0)))
         if self.reset_cfg is not None:
-            self._note_cfg(self.reset_cfg)
+            self._note_cfg(self.reset_cfg, set_autoreset=True)
         self.py_order_stale = True

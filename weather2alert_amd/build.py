@@ -62,7 +62,7 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > m for d in _dep_files())
 
 
-STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_step_dispatch.hip.h")
+STEP_SOURCES = ("w2a_common.hip.h", "w2a_step.hip.h", "w2a_step64.hip.h", "w2a_step_dispatch.hip.h", "w2a_bookkeeping.h")
 
 
 def source_sha(files: tuple = STEP_SOURCES) -> str:

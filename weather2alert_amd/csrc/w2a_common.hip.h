@@ -3,6 +3,8 @@
 #ifndef W2A_COMMON_HIP_H
 #define W2A_COMMON_HIP_H
 
+#include "w2a_bookkeeping.h"
+
 #ifndef LANES
 #define LANES 4  // lanes per env: 8, 4, 2 or 1 (A/B-tested on MI355X)
 #endif
@@ -190,19 +192,10 @@ struct w2a_env {
   const float *rm_wscale;
   const uint32_t *rm_rowflag;
   const float *rm_xs;
-  int rm_valid;                  // the tile list belongs to the current episode's visiting order
-  int last_rollout_kernel;       // W2A_Q_LAST_ROLLOUT_KERNEL
-  int last_step_kernel;          // W2A_Q_LAST_STEP_KERNEL
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
-  int perm_valid;
-  // which form of the per-env step state is current (see StateArrays): the canonical arrays, the lock-step mirror,
-  // or both; uni_t = the day every env is on when the batch is known to be in lock step (-1: not known)
-  int pk_valid, canon_valid, pk_static_ok;
-  int32_t uni_t, uni_nd, pk_t, b0_max;
-  int64_t budget_bound;  // no env's budget exceeds this (INT64_MAX: unknown)
-  int64_t budget_bound_known;  // its last known value (w2a_set_budget_bound restores knowledge after a reset with
-                               // caller-chosen budgets in device memory)
-  int graph_captured;    // a w2a_step of this handle was recorded into a hipGraph: canonical form only from then on
+  // which form of the per-env step state is current, what is known about days and budgets, which derived structures
+  // are still valid: w2a_bookkeeping.h (plain C++, exercised on the CPU under sanitizers by tests/test_bookkeeping_cpu.py)
+  W2aBook bk;
   int pm_kernel;         // W2A_PM_* : which posterior-mean reward kernel w2a_posterior_mean_reward launches
   int w_tail_used;       // some coefficient row uses slot 28, 30 or 31 (scanned once by w2a_create)
 };

@@ -134,23 +134,24 @@ size_t w2a_state_bytes(int64_t num_envs) {
   return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n) + 2 * align256(8 * n);
 }
 
-// ---- which form of the step state is current (StateArrays::pk_hot / pk_c, w2a_common.hip.h) -------------------------
+// ---- which form of the step state is current (StateArrays::pk_hot / pk_c): decided in w2a_bookkeeping.h; this is its
+// device side, the two conversion launches on the caller's stream
+struct HipDev {
+  w2a_env *env;
+  hipStream_t s;
+  void pack_state() {
+    hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);
+  }
+  void unpack_state(int32_t t, int32_t n_days) {
+    hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, t, n_days);
+  }
+};
 static void ensure_canonical(w2a_env *env, hipStream_t s) {
-  if (env->canon_valid) return;
-  hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, env->pk_t,
-                     env->uni_nd);
-  env->canon_valid = 1;
-}
-// the canonical arrays are about to be modified by something that does not maintain the lock-step mirror
-static void canonical_modified(w2a_env *env, bool keeps_lockstep = false) {
-  env->pk_valid = 0;
-  if (!keeps_lockstep) env->uni_t = -1;
+  HipDev d{env, s};
+  bk_ensure_canonical(env->bk, d);
 }
 static void note_budgets(w2a_env *env, int64_t cand, int sample_mode, int sticky) {
-  if (env->budget_bound != INT64_MAX) env->budget_bound_known = env->budget_bound;
-  if (cand < 0 || (sample_mode == W2A_BUDGET_CENTERED && sticky)) { env->budget_bound = INT64_MAX; return; }  // unknown /
-  if (sample_mode == W2A_BUDGET_CENTERED) cand = cand + cand / 2 + 1;        // a sticky centred budget is a random walk
-  if (cand > env->budget_bound) env->budget_bound = cand;
+  bk_note_budgets(env->bk, cand, sample_mode == W2A_BUDGET_CENTERED, sticky != 0);
 }
 __global__ void k_table_scan(const int32_t *n_days, const int32_t *B0, int32_t rows, int32_t *out) {  // out: min nd, max nd, max B0
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,18 +216,15 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.stepc = reinterpret_cast<u3 *>((char *)h->st.hot3 + align256(12 * (size_t)num_envs));
   h->st.pk_hot = reinterpret_cast<uint2 *>((char *)h->st.stepc + align256(12 * (size_t)num_envs));
   h->st.pk_c = reinterpret_cast<uint2 *>((char *)h->st.pk_hot + align256(8 * (size_t)num_envs));
-  h->pk_valid = 0; h->canon_valid = 1; h->uni_t = -1; h->uni_nd = -1; h->pk_t = 0; h->b0_max = 0; h->budget_bound = 0;
-  h->budget_bound_known = 0; h->graph_captured = 0;
-  h->pk_static_ok = (t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22)) ? 1 : 0;
+  bk_init(h->bk, t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22), -1, 0);
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
   h->order = nullptr;
   h->prep = nullptr;
-  h->perm_valid = 0;
   h->pm_kernel = W2A_PM_VECTOR;
   h->xmax_ws = nullptr;
-  h->order_cursor = nullptr; h->rm_ws = nullptr; h->rm_valid = 0; h->last_rollout_kernel = -1; h->last_step_kernel = -1;
+  h->order_cursor = nullptr; h->rm_ws = nullptr;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
@@ -251,8 +249,8 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
     hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, t->n_days, t->B0, rows, d_scan);
     if (e5 == hipSuccess) e5 = hipMemcpy(scan, d_scan, sizeof(scan), hipMemcpyDeviceToHost);
     if (e5 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: table scan failed: %s", hipGetErrorString(e5)); }
-    h->uni_nd = (scan[0] == scan[1] && scan[0] > 0) ? scan[0] : -1;
-    h->b0_max = scan[2];
+    h->bk.uni_nd = (scan[0] == scan[1] && scan[0] > 0) ? scan[0] : -1;
+    h->bk.b0_max = scan[2];
   }
   *out = h;
   return W2A_OK;
@@ -267,15 +265,9 @@ static unsigned grid_for(int64_t n) {
 }
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
-  if (a.from_tuples != 2) env->perm_valid = 0;  // new episode tuples: the column grouping is stale
-  // a full reset rewrites every env's canonical words (it reads only `cold`, which is never stale); a masked reset
-  // and w2a_observe read the rest as well
-  if (a.mask || a.from_tuples == 2) ensure_canonical(env, (hipStream_t)stream);
-  if (a.from_tuples != 2) {
-    env->rm_valid = 0;  // new episodes: the feature-row tile list of the matrix-core rollout is stale
-    env->canon_valid = 1;
-    canonical_modified(env);
-    if (!a.mask && env->uni_nd > 0) env->uni_t = 0;  // every env on day 0 of an episode of the one length there is
+  {
+    HipDev d{env, (hipStream_t)stream};
+    bk_reset(env->bk, d, a.from_tuples == 2, a.mask != nullptr);
   }
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
@@ -292,7 +284,7 @@ int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, cons
   memset(&a, 0, sizeof(a));
   a.county_w = county_w; a.year_i = year_i; a.coef_col = coef_col; a.sample = sample; a.budget = budget;
   a.mask = mask; a.obs = obs; a.from_tuples = 1;
-  note_budgets(env, budget ? -1 : env->b0_max, W2A_BUDGET_FIXED, 0);  // caller's budgets live in device memory: unknown
+  note_budgets(env, budget ? -1 : env->bk.b0_max, W2A_BUDGET_FIXED, 0);  // caller's budgets live in device memory: unknown
   return launch_reset(env, a, stream);
 }
 
@@ -314,7 +306,7 @@ int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augm
   int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   a.mask = mask; a.obs = obs; a.from_tuples = 0; a.restart = restart_episodes ? 1 : 0;
-  note_budgets(env, budget_kw >= 0 ? budget_kw : env->b0_max, sample_budget_mode, sticky);
+  note_budgets(env, budget_kw >= 0 ? budget_kw : env->bk.b0_max, sample_budget_mode, sticky);
   return launch_reset(env, a, stream);
 }
 
@@ -324,7 +316,7 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
   int rc = fill_cfg(env, env->autoreset, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   env->has_autoreset = 1;
-  note_budgets(env, budget_kw >= 0 ? budget_kw : env->b0_max, sample_budget_mode, sticky);
+  bk_set_autoreset(env->bk, budget_kw >= 0 ? budget_kw : env->bk.b0_max, sample_budget_mode == W2A_BUDGET_CENTERED, sticky != 0);
   return W2A_OK;
 }
 
@@ -360,9 +352,10 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   size_t cub_bytes = cub_sort_bytes(env->n);
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  ensure_canonical(env, s);
-  canonical_modified(env, true);  // a relabelling: the batch stays in lock step
-  env->rm_valid = 0;
+  {
+    HipDev d{env, s};
+    bk_sort(env->bk, d);  // a relabelling: the batch stays in lock step; grouping and tile lists go stale
+  }
   hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
@@ -373,7 +366,6 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
-  env->perm_valid = 0;  // every env index now holds another episode: the column grouping is stale
   return W2A_OK;
 }
 
@@ -472,14 +464,14 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   HIP_TRY(hipGetLastError());
   env->inv = k_in;
   env->perm = perm;
-  env->perm_valid = 1;
+  bk_grouped(env->bk);
   return W2A_OK;
 }
 
 int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream) {
   if (!env || !actions || !reward) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: NULL argument");
   if (action_dtype < W2A_ACT_I32 || action_dtype > W2A_ACT_U8) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: bad action_dtype");
-  if (!env->perm_valid)
+  if (!env->bk.perm_valid)
     return fail(W2A_ERR_STATE, "w2a_posterior_mean_reward: call w2a_group_by_column after every reset (the grouping of "
                                "envs by coefficient column is stale)");
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_posterior_mean_reward: not available with corrected-semantics flags");
@@ -558,7 +550,7 @@ int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   HIP_TRY(hipGetLastError());
   env->order = order;
   env->order_cursor = cnt;
-  env->rm_valid = 0;
+  bk_order_set(env->bk);
   return W2A_OK;
 }
 
@@ -610,7 +602,7 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
   HIP_TRY(hipGetLastError());
   env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq; env->rm_wscale = wscale; env->rm_rowflag = rowflag;
   env->rm_xs = xs;
-  env->rm_valid = 1;
+  bk_rm_prepared(env->bk);
   return W2A_OK;
 }
 
@@ -640,14 +632,14 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   a.ret_snapshot = ret_snapshot;
   a.order = env->order;
   hipStream_t s = (hipStream_t)stream;
-  const int32_t lockstep_day = env->uni_t;  // -1: the handle does not know every env to be on the same day
-  ensure_canonical(env, s);
-  canonical_modified(env, true);
-  // a batch in lock step stays in lock step: every env runs the same n_steps days, or all of them reach their last day
-  env->uni_t = (lockstep_day >= 0 && lockstep_day + n_steps < env->uni_nd) ? lockstep_day + n_steps : -1;
+  HipDev dv{env, s};
+  // -1: the handle does not know every env to be on the same day. A batch in lock step stays in lock step: every env
+  // runs the same n_steps days, or all of them reach their last day
+  const int32_t lockstep_day = bk_rollout_begin(env->bk, dv, n_steps);
+  const int rkernel = bk_rollout_kernel(env->bk, lockstep_day, env->tb.fixes != 0, W2A_ROLLOUT_MFMA != 0, W2A_ROLLOUT_WIDE != 0);
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
-  if (env->rm_valid && a.order && !env->tb.fixes && lockstep_day >= 0 && W2A_ROLLOUT_MFMA) {
+  if (rkernel == W2A_BK_ROLLOUT_MFMA) {
     // the table-sourced part of the logits on the int8 matrix cores (w2a_rollout_mfma.hip.h): needs the episode's
     // feature-row tile list (w2a_rollout_mfma_prepare) and a batch in lock step
     RmArgs ra;
@@ -656,10 +648,8 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());
-    env->last_rollout_kernel = 2;
     return W2A_OK;
   }
-  env->last_rollout_kernel = (W2A_ROLLOUT_WIDE && a.order) ? 1 : 0;
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
   HIP_TRY(hipGetLastError());
   return W2A_OK;
@@ -676,7 +666,7 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
     return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: tabular policy needs table [T][table_R] and table_R > 0");
   if ((alert_mask || attempt_mask) && mask_words * 32 < env->tb.T)
     return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: alert_mask / attempt_mask need ceil(T/32) words per env");
-  if (!env->perm_valid)
+  if (!env->bk.perm_valid)
     return fail(W2A_ERR_STATE, "w2a_rollout_posterior_mean: call w2a_group_by_column after every reset");
   if (env->tb.fixes) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: not available with corrected-semantics flags");
   // not applicable (more draws than one staging pass holds; vector form: coefficients on slots 28/30/31; the fp64 matrix
@@ -702,10 +692,8 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   pa.perm = env->perm; pa.tiles = env->tiles; pa.n_tiles = env->n_tiles; pa.wd = env->wd;
   hipStream_t s = (hipStream_t)stream;
   {
-    const int32_t lockstep_day = env->uni_t;
-    ensure_canonical(env, s);
-    canonical_modified(env, true);
-    env->uni_t = (lockstep_day >= 0 && lockstep_day + n_steps < env->uni_nd) ? lockstep_day + n_steps : -1;
+    HipDev dv{env, s};
+    (void)bk_rollout_begin(env->bk, dv, n_steps);
   }
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
@@ -763,29 +751,25 @@ int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
 int w2a_query(w2a_env *env, int what) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_query: NULL handle");
   switch (what) {
-    case W2A_Q_LOCKSTEP_DAY: return env->uni_t;
-    case W2A_Q_PACKED_ELIGIBLE: return (env->pk_static_ok && env->budget_bound <= 65535 && env->uni_nd > 0) ? 1 : 0;
-    case W2A_Q_PACKED_CURRENT: return env->pk_valid;
-    case W2A_Q_CANONICAL_CURRENT: return env->canon_valid;
-    case W2A_Q_LAST_ROLLOUT_KERNEL: return env->last_rollout_kernel;
-    case W2A_Q_LAST_STEP_KERNEL: return env->last_step_kernel;
+    case W2A_Q_LOCKSTEP_DAY: return env->bk.uni_t;
+    case W2A_Q_PACKED_ELIGIBLE: return bk_packed_eligible(env->bk) ? 1 : 0;
+    case W2A_Q_PACKED_CURRENT: return env->bk.pk_valid;
+    case W2A_Q_CANONICAL_CURRENT: return env->bk.canon_valid;
+    case W2A_Q_LAST_ROLLOUT_KERNEL: return env->bk.last_rollout_kernel;
+    case W2A_Q_LAST_STEP_KERNEL: return env->bk.last_step_kernel;
     default: return fail(W2A_ERR_ARG, "w2a_query: unknown item");
   }
 }
 
 int w2a_invalidate(w2a_env *env) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
-  if (env->budget_bound != INT64_MAX) env->budget_bound_known = env->budget_bound;
-  env->pk_valid = 0; env->canon_valid = 1; env->uni_t = -1; env->perm_valid = 0; env->budget_bound = INT64_MAX;
-  env->rm_valid = 0;  // feature rows may have changed behind the handle: the matrix-core rollout's tile list is stale
+  bk_invalidate(env->bk);
   return W2A_OK;
 }
 
 int w2a_set_budget_bound(w2a_env *env, int64_t bound) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_set_budget_bound: NULL handle");
-  if (bound < 0) { env->budget_bound = INT64_MAX; return W2A_OK; }
-  const int64_t prev = env->budget_bound != INT64_MAX ? env->budget_bound : env->budget_bound_known;
-  env->budget_bound = bound > prev ? bound : prev;  // budgets of earlier episodes may live on as sticky budgets
+  bk_set_budget_bound(env->bk, bound);
   return W2A_OK;
 }
 

@@ -19,7 +19,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (!no_obs && !obs) return fail(W2A_ERR_ARG, "w2a_step: obs is NULL (pass W2A_STEP_NO_OBS for reward-only)");
   if (!no_obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_step: obs must be 16-B aligned");
   if (autoreset && !env->has_autoreset) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_AUTORESET needs w2a_set_autoreset first");
-  if (autoreset) env->perm_valid = 0;  // envs that finish draw new coefficient columns inside the kernel
   StepArgs a;
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
@@ -32,61 +31,49 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_SKIP_FINISHED goes with W2A_STEP_REWARD_GIVEN (policy loops)");
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
-  // the day every env is on after this call, if the batch is (still) known to be in lock step: a plain step moves all
-  // of them to the next day; the terminal step, an in-kernel autoreset or unknown state ends the knowledge
-  int32_t uni_next = (!autoreset && env->uni_t >= 0 && env->uni_t + 1 < env->uni_nd) ? env->uni_t + 1 : -1;
   // Stream capture (hipGraph): a captured step is replayed later without the host's bookkeeping being run again, so
   // nothing that depends on it may be baked into the graph -- the packed variant takes the day as a kernel ARGUMENT.
   // Under capture the canonical kernels run (they read the day from memory), and a handle that has ever been captured
-  // keeps to the canonical form for good (a replay advances days behind the host's back).
+  // keeps to the canonical form for good (a replay advances days behind the host's back): w2a_bookkeeping.h, bk_step.
+  bool capturing = false;
   {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-      if (!env->canon_valid)
-        return fail(W2A_ERR_STATE, "w2a_step: stream capture started while the step state is in its packed lock-step form; "
-                                   "call w2a_get_state (or any entry point that reads the canonical state) before capturing");
-      env->graph_captured = 1;
-    } else {
-      (void)hipGetLastError();
-    }
-    if (env->graph_captured) uni_next = -1;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
+    else (void)hipGetLastError();
   }
 #if W2A_F64_SIGMOID
   if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
+  const bool wide = false;
 #else
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
-  const bool wide = given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS;
-  if (wide && !(flags & W2A_STEP_CLASSIC)) {
+  const bool wide = (given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS) && !(flags & W2A_STEP_CLASSIC);
+#endif
+  // which kernel, on which form of the per-env state; the form conversions (k_pack_state / k_unpack_state) are launched
+  // from inside, and the day every env is on after this call is recorded there
+  HipDev dv{env, s};
+  const BkStepPlan plan = bk_step(env->bk, dv, wide, autoreset, given, (flags & W2A_STEP_UNPACKED) != 0, capturing);
+  if (plan.kernel < 0)
+    return fail(W2A_ERR_STATE, "w2a_step: stream capture started while the step state is in its packed lock-step form; "
+                               "call w2a_get_state (or any entry point that reads the canonical state) before capturing");
+#if !W2A_F64_SIGMOID
+  if (plan.kernel != W2A_BK_STEP_CLASSIC) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
     const int64_t per_wg = (int64_t)BLOCK * W2A_S64_TILES;
     const int64_t tiles = (env->n + per_wg - 1) / per_wg;
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
-    // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
-    const bool packed = !given && !autoreset && !(flags & W2A_STEP_UNPACKED) && env->pk_static_ok && env->uni_t >= 0 &&
-                        env->budget_bound <= 65535 && !env->graph_captured;
-    if (packed) {
-      if (!env->pk_valid) {  // entering the packed form (once per episode): the canonical arrays are current
-        hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);
-        env->pk_valid = 1;
-      }
-      a.uni_t = env->uni_t; a.uni_nd = env->uni_nd;
+    if (plan.kernel == W2A_BK_STEP_PACKED) {
+      // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
+      a.uni_t = plan.uni_t; a.uni_nd = plan.uni_nd;
       if (env->tb.fixes) {  // corrected-semantics flags: their own variants, the faithful kernels carry none of the code
         if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, false, true>), grid64, block, 0, s, a);
         else hipLaunchKernelGGL((k_step64<true, false, true, false, true>), grid64, block, 0, s, a);
       } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
       HIP_TRY(hipGetLastError());
-      env->last_step_kernel = 2;
-      env->canon_valid = 0;
-      env->pk_t = uni_next >= 0 ? uni_next : env->uni_t;  // the terminal step leaves t where it is (env.py:256-259)
-      env->uni_t = uni_next;
       return W2A_OK;
     }
-    ensure_canonical(env, s);
-    canonical_modified(env, true);
-    env->uni_t = uni_next;
     if (given) {
       if (no_obs) hipLaunchKernelGGL((k_step64<false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, true>), grid64, block, 0, s, a);
@@ -106,13 +93,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
       else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
     }
     HIP_TRY(hipGetLastError());
-    env->last_step_kernel = 1;
     return W2A_OK;
   }
 #endif
-  ensure_canonical(env, s);
-  canonical_modified(env, true);
-  env->uni_t = uni_next;
 #define W2A_LAUNCH(AR, OB) \
   do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, true>), grid, block, 0, s, a); \
        else hipLaunchKernelGGL((k_step<AR, OB, false>), grid, block, 0, s, a); } while (0)
@@ -120,7 +103,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   else { if (no_obs) W2A_LAUNCH(false, false); else W2A_LAUNCH(false, true); }
 #undef W2A_LAUNCH
   HIP_TRY(hipGetLastError());
-  env->last_step_kernel = 0;
   return W2A_OK;
 }
 
