@@ -76,6 +76,8 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the reported extras (always-alert policy, sorted episode order, posterior-mean reward)")
+    p.add_argument("--no-calibration", action="store_true",
+                   help="skip the in-process copy-rate / access-pattern probe that precedes the warm-up steps")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: the workload's env count per GPU (default); strong: that count split over the GPUs")
@@ -334,37 +336,110 @@ def run_stub(args, rank, world):
         torch.cuda.set_device(device)
     wdist.init_from_env(args.backend, device if use_gpu else None)
     n = args.num_envs or WORKLOADS["launcher_stub"][1]
+    if args.scaling == "strong":  # a fixed total split over the ranks
+        start, stop = wdist.shard_range(n, rank, world)
+        if (stop - start) * world != n:
+            raise SystemExit("--scaling strong needs an env count divisible by the number of GPUs")
+        n = stop - start
+    import torch.distributed as td
+
+    seen = td.get_world_size() if td.is_initialized() else 1
+    if seen != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the process group has {seen} rank(s)", file=sys.stderr, flush=True)
+        return 4
     gather = wdist.ReturnGatherer(n, device)
     gid0 = rank * n
     returns = -(torch.arange(gid0, gid0 + n, dtype=torch.float32, device=device) % 97)
     T, coll = 153, []
+
+    def loop(with_gather):
+        t0 = time.perf_counter()
+        for s in range(1, args.steps + 1):
+            returns.add_(0.0)  # stands in for a step
+            if with_gather and s % T == 0:
+                c0 = time.perf_counter()
+                gather.gather(returns)
+                coll.append(time.perf_counter() - c0)
+        return time.perf_counter() - t0
+
+    single = None
+    if world > 1:  # rank 0 alone, the others idle at the barrier (the real workload's `single_gpu_value`)
+        wdist.barrier()
+        if rank == 0:
+            single = float(n) * args.steps / max(loop(False), 1e-9)
+        wdist.barrier()
     wdist.barrier()
-    t0 = time.perf_counter()
-    for s in range(1, args.steps + 1):
-        if s % T == 0:
-            c0 = time.perf_counter()
-            gather.gather(returns)
-            coll.append(time.perf_counter() - c0)
+    wall = loop(True)
     wdist.barrier()
-    wall = wdist.max_over_ranks(time.perf_counter() - t0, device)
+    wall = wdist.max_over_ranks(wall, device)
+    no_coll = None
+    if world > 1:
+        wdist.barrier()
+        w2 = loop(False)
+        wdist.barrier()
+        no_coll = wdist.max_over_ranks(w2, device)
     allr = gather.gather(returns)
     expect = -(torch.arange(0, n * world, dtype=torch.float32, device=device) % 97)
     ok = bool(torch.equal(allr, expect))
-    import torch.distributed as td
-
-    seen = td.get_world_size() if td.is_initialized() else 1
     if rank == 0:
+        total = float(n) * world * args.steps
         print(json.dumps({
-            "metric": "env_steps_per_sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall * 1e3 / max(args.steps, 1), "higher_is_better": True,
+            "metric": "env_steps_per_sec", "value": total / wall, "unit": "stub steps/s (no env work)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / max(args.steps, 1), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "n/a", "data": "stub",
-            "config": {"workload": WORKLOADS["launcher_stub"][3], "num_envs_per_gpu": n, "backend": args.backend},
+            "config": {"workload": WORKLOADS["launcher_stub"][3], "num_envs_per_gpu": n, "num_envs_total": n * world,
+                       "backend": args.backend},
+            "per_gpu_value": total / wall / world, "single_gpu_value": single,
+            "efficiency_vs_rank0_alone": (total / wall / world / single) if single else None,
+            "weak_efficiency": (total / wall / world / single) if (single and args.scaling == "weak") else None,
+            "no_collective_value": (total / no_coll) if no_coll else None,
+            "collective_overhead_frac": ((wall - no_coll) / wall) if no_coll else None,
             "rccl_ranks_seen": seen, "collective_ms": (sum(coll) / len(coll) * 1e3) if coll else None,
             "gather_ok": ok, "stub": True}), flush=True)
     wdist.barrier()
     if td.is_initialized():
         td.destroy_process_group()
     return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------ box calibration
+def box_calibration(env, dt, ct, packed, torch):
+    """What THIS box delivers in THIS process, measured right before the run it is compared with (the GPU boxes of one
+    pool differ by 7-10 % on the same command): the rate of a plain float4 copy of 1 GiB, and the time of an arithmetic-
+    free program that issues the step kernel's traffic on the env's own tables and its own episode tuples
+    (tools/fabric_probe.hip as a library: streams only / gathers only / both). Measurement code, not part of the env."""
+    import ctypes as C
+
+    from weather2alert_amd import build as wbuild
+
+    out = {"source": "tools/fabric_probe.hip " + " ".join(wbuild.PROBE_FLAGS) + (" -DPROBE_PACKED" if packed else "") +
+                     ", in this process, on this run's tables and episode tuples, before the warm-up steps"}
+    try:
+        lib = C.CDLL(wbuild.build_probe_lib(packed=packed))
+        lib.w2a_probe_last_error.restype = C.c_char_p
+        lib.w2a_probe_copy.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+        lib.w2a_probe_step_pattern.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+        stream = torch.cuda.current_stream().cuda_stream
+        gbs = C.c_float(0.0)
+        if lib.w2a_probe_copy(1 << 30, 5, C.byref(gbs), stream) != 0:
+            raise RuntimeError(lib.w2a_probe_last_error().decode())
+        out["copy_gbs"] = float(gbs.value)
+        st = env.state()
+        xrow = (st["county_w"] * ct.Y + st["year_i"]).to(torch.int32).contiguous()
+        wrow = (st["coef_col"] * ct.n_samples + st["sample"]).to(torch.int32).contiguous()
+        n256 = env.num_envs // 256 * 256
+        if n256 and ct.n_obs == 29:
+            us = (C.c_float * 3)()
+            if lib.w2a_probe_step_pattern(dt.X.data_ptr(), ct.S_w * ct.Y, ct.T, dt.W.data_ptr(), xrow.data_ptr(), wrow.data_ptr(),
+                                          n256, 3, 100, us, stream) != 0:
+                raise RuntimeError(lib.w2a_probe_last_error().decode())
+            out["probe_us"] = {"streams_only": float(us[0]), "gathers_only": float(us[1]), "streams_and_gathers": float(us[2]),
+                               "envs": n256}
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001  (a reported calibration, never fatal)
+        out["error"] = repr(e)
+    return out
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -577,6 +652,10 @@ def main():
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if args.backend == 'gloo' else local}")
     torch.cuda.set_device(device)
     wdist.init_from_env(args.backend, device)
+    seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if seen != args.gpus:  # a group smaller than asked for would be benchmarked as if it were whole
+        print(f"bench.py: --gpus {args.gpus} but the process group has {seen} rank(s)", file=sys.stderr, flush=True)
+        return 4
     if local == 0:  # one rank per node (re)builds libw2a.so if its sources are newer; the others wait and load it
         wbuild.build_lib()
     wdist.barrier()
@@ -602,14 +681,22 @@ def main():
     env.reset(seed=args.seed)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
+    # this box's memory side, in this process, on this run's access pattern (reads the state once: right after a reset
+    # the canonical words are current, so the handle is left as it was)
+    will_pack = bool(env._lib.w2a_query(env._h, 1)) and env.step_kernel_name == "k_step64" and args.step_kernel != "unpacked" \
+        and env._host_auto
+    calib = None if args.no_calibration else box_calibration(env, dt, ct, will_pack, torch)
     T = ct.T
     stepno = 0
     coll_ev = []
 
+    use_gather = True  # the extra run of item (a) below switches the collective off
+
     def gather_returns():
         # world > 1: the collective is enqueued without blocking the launch stream and overlaps the next episode's
         # steps (RCCL runs it on the process group's stream); it is waited for before the next one and at the end
-        gather.gather(env._final_return, async_op=world > 1)
+        if use_gather:
+            gather.gather(env._final_return, async_op=world > 1)
 
     seg_events = []  # (start, end) HIP events around the step launches of each episode inside the timed region
     seg_on = False
@@ -667,33 +754,71 @@ def main():
         _w0.record(); _w1.record(); _w1.synchronize(); _w0.elapsed_time(_w1)
     import gc
 
-    gc.collect()
-    gc.disable()  # no collector pause inside the timed region (re-enabled right after it)
-    wdist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is None:
-        seg_on = True
-        for _ in range(args.steps):
+    def timed_region(segments: bool):
+        """EXACTLY args.steps steps between barrier + device synchronisation on both sides; (wall seconds on this rank,
+        device milliseconds). segments: also record the per-episode HIP events of the headline's kernel timing."""
+        nonlocal seg_on, stepno
+        gc.collect()
+        gc.disable()  # no collector pause inside the timed region (re-enabled right after it)
+        wdist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_start = time.perf_counter()
+        e0.record()
+        if graph is None:
+            seg_on = segments
+            for _ in range(args.steps):
+                one_step()
+            seg_on = False
+        else:
+            for _ in range(args.steps // args.graph):
+                graph.replay()
+                before = stepno
+                stepno += args.graph
+                if stepno // T != before // T:
+                    gather_returns()
+        gather.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        wdist.barrier()
+        w = time.perf_counter() - t_start
+        gc.enable()
+        return w, e0.elapsed_time(e1)
+
+    # ---- multi-GPU: the same workload on ONE GPU of this very job, before the headline (the other ranks wait idle at a
+    # barrier, so rank 0 has its GPU, its PCIe link and the host to itself): the denominator of `weak_efficiency`
+    single = None
+    if world > 1 and graph is None:
+        wdist.barrier()
+        if rank == 0:
+            use_gather = False
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            single = float(n) * args.steps / (time.perf_counter() - t1)
+            use_gather = True
+        wdist.barrier()
+        # every rank back on the same day of an episode (rank 0 ran ahead): a whole-batch reset and the W warm-up steps
+        # again, untimed
+        env.reset(seed=args.seed + 1)
+        stepno = 0
+        for _ in range(args.warmup):
             one_step()
-        seg_on = False
-    else:
-        for _ in range(args.steps // args.graph):
-            graph.replay()
-            before = stepno
-            stepno += args.graph
-            if stepno // T != before // T:
-                gather_returns()
-    gather.wait()
-    ev1.record()
-    torch.cuda.synchronize()
-    wdist.barrier()
-    wall = time.perf_counter() - t0
-    gc.enable()
+        gather.wait()
+        torch.cuda.synchronize()
+
+    wall, dev_ms = timed_region(segments=True)
     wall = wdist.max_over_ranks(wall, device)
-    dev_ms = ev0.elapsed_time(ev1)
+    stepno_head = stepno  # where the headline region ended (the extra region below moves on)
+    # ---- multi-GPU: the same K steps once more WITHOUT the return all-gather: what the collective costs end to end
+    no_coll = None
+    if world > 1:
+        use_gather = False
+        w2, _ = timed_region(segments=False)
+        no_coll = wdist.max_over_ranks(w2, device)
+        use_gather = True
     status = env.check_status()
     mean_ret = float(gather.mean(env._final_return).item())
     collective_ms = min(a.elapsed_time(b) for a, b in coll_ev) if coll_ev else None
@@ -709,7 +834,7 @@ def main():
         kernel_us = sum(a.elapsed_time(b) for a, b in segs) * 1e3 / (len(segs) * (T - 1))
         kernel_timing = (f"HIP events on the launch stream around the {T - 1} back-to-back step launches of each of the "
                          f"{len(segs)} whole episodes inside the timed region (reset kernels and collectives excluded)")
-    elif graph is None and args.steps < T - 1 and (stepno - args.steps) // T == (stepno - 1) // T and (stepno % T) != 0:
+    elif graph is None and args.steps < T - 1 and (stepno_head - args.steps) // T == (stepno_head - 1) // T and (stepno_head % T) != 0:
         # a timed region shorter than an episode that did not cross an episode boundary (the driver's --steps 20): its
         # launches are nothing but step kernels, so the HIP events around the region itself are the measurement
         kernel_us = dev_ms * 1e3 / args.steps
@@ -776,6 +901,13 @@ def main():
                                                " (the N = 1 default is configs2, a different table shape: compare "
                                                "multi-GPU values with THIS workload on one GPU)" if world > 1 else None},
             "per_gpu_value": total_env_steps / wall / world,
+            # multi-GPU runs judge themselves (None on one GPU): the same workload on rank 0's GPU alone while the other
+            # ranks idle at a barrier, and the same K steps once more without the return all-gather
+            "single_gpu_value": single,
+            "efficiency_vs_rank0_alone": (total_env_steps / wall / world / single) if single else None,
+            "weak_efficiency": (total_env_steps / wall / world / single) if (single and args.scaling == "weak") else None,
+            "no_collective_value": (total_env_steps / no_coll) if no_coll else None,
+            "collective_overhead_frac": ((wall - no_coll) / wall) if no_coll else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["bytes_per_launch"],
@@ -793,6 +925,16 @@ def main():
                                                       "kernel_avg_us", "src_sha", "commit", "profile")},
                          "traffic_note": traffic_note, "kernel_src_sha": src_sha,
                          "probe_ceiling": probe,
+                         # measured in THIS process on THIS box before the warm-up steps (box_calibration)
+                         "copy_gbs_this_box": None if not calib else calib.get("copy_gbs"),
+                         "probe_us_this_box": None if not calib else calib.get("probe_us"),
+                         "kernel_over_probe": (per_launch_s * 1e6 / calib["probe_us"]["streams_and_gathers"])
+                         if calib and calib.get("probe_us") else None,
+                         "frac_of_copy_rate_this_box": (achieved / calib["copy_gbs"]) if calib and calib.get("copy_gbs") else None,
+                         "calibration": None if not calib else {k: v for k, v in calib.items() if k in ("source", "error")},
+                         "traffic_provenance": None if traffic is None else
+                         "REPLAYED from profiles/traffic_latest.json (rocprofv3 --pmc passes of the same command on the "
+                         "same kernel sources, src_sha checked; counters cannot be read inside this process)",
                          "frac_of_measured_copy_bw": achieved / 6290.0,
                          "frac_with_unpacked_161B_model": compulsory_bytes(ct.n_obs, not args.no_obs)["total"] * n
                          / per_launch_s / 1e9 / HBM_PEAK_GBS,

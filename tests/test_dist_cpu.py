@@ -105,6 +105,10 @@ def test_bench_launches_itself_for_several_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2 and out["gather_ok"] and out["stub"]
     assert out["steps"] == 306 and out["collective_ms"] is not None and out["scaling"] == "weak"
+    # a multi-rank line judges itself: the same workload on rank 0 alone, the same steps without the collective
+    for k in ("single_gpu_value", "weak_efficiency", "efficiency_vs_rank0_alone", "no_collective_value", "collective_overhead_frac"):
+        assert out[k] is not None, k
+    assert out["single_gpu_value"] > 0 and out["weak_efficiency"] > 0 and out["collective_overhead_frac"] < 1
     # a mismatching launcher environment is refused, not silently benchmarked on one rank
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "launcher_stub",
                           "--backend", "gloo"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"),
@@ -130,6 +134,17 @@ def test_bench_launcher_eight_ranks_and_a_rank_that_dies_at_startup():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 8 and out["rccl_ranks_seen"] == 8 and out["gather_ok"]
     assert out["config"]["num_envs_per_gpu"] == 1024 and out["collective_ms"] is not None
+    # strong scaling on the same 8 ranks: a fixed total (8192) split over the ranks, the all-gather reassembles it
+    st = subprocess.run(base[:-2] + ["--num-envs", "8192", "--scaling", "strong"], capture_output=True, text=True, env=env,
+                        timeout=280)
+    assert st.returncode == 0, (st.stdout[-2000:], st.stderr[-2000:])
+    so = json.loads([ln for ln in st.stdout.splitlines() if ln.startswith("{")][-1])
+    assert so["scaling"] == "strong" and so["config"]["num_envs_per_gpu"] == 1024 and so["config"]["num_envs_total"] == 8192
+    assert so["gather_ok"] and so["rccl_ranks_seen"] == 8 and so["weak_efficiency"] is None
+    assert so["efficiency_vs_rank0_alone"] is not None
+    odd = subprocess.run(base[:-2] + ["--num-envs", "8190", "--scaling", "strong"], capture_output=True, text=True, env=env,
+                         timeout=120)
+    assert odd.returncode != 0 and "divisible" in (odd.stderr + odd.stdout)
     t0 = time.time()
     bad = subprocess.run(base + ["--fail-rank", "5"], capture_output=True, text=True, env=env, timeout=120)
     assert bad.returncode == 3 and time.time() - t0 < 60, (bad.returncode, time.time() - t0, bad.stderr[-1500:])

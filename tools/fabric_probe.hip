@@ -6,6 +6,9 @@
 //            128-B line of a 1 MB table (the day slice), reduced to one float so the loads cannot be dropped
 //   both   : one kernel doing both per env (what k_step64 does, minus the arithmetic)
 // Build + run (no torch):  hipcc --offload-arch=gfx950 -O3 tools/fabric_probe.hip -o /tmp/fabric_probe && /tmp/fabric_probe
+// -DPROBE_LIB: no main(); extern "C" entry points for bench.py, which runs the probe IN ITS OWN PROCESS on the tables and
+// the episode tuples of the env it is about to time (weather2alert_amd/build.py: build_probe_lib -> _lib/libw2a_probe.so),
+// so that every bench line carries this box's own copy rate and probe time next to the kernel's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -35,13 +38,20 @@ __device__ const float4 *g_Wrt;
 #define P_ROUNDS 4
 #endif
 #define P_PASS_ENVS (P_ROUNDS * 8)
+#ifdef PROBE_LIB
+__constant__ uint32_t g_rows_per_day;  // feature rows per day slice of the caller's table
+#endif
 template <bool STREAM, bool GATHER>
 __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc, const int32_t *act, u3 *hot_out,
                                                   float *reward, uint8_t *done, float *obs, const float4 *W,
                                                   const float4 *X, const uint32_t *wrow, const uint32_t *xrow, int64_t n) {
   const int64_t n_raw = n;
 #ifdef PROBE_DAYS
+#ifdef PROBE_LIB
+  X += (size_t)(n >> 40) * g_rows_per_day * 8;
+#else
   X += (size_t)(n >> 40) * 8206 * 8;  // day slice in the upper bits of n (keeps the signature)
+#endif
   n &= (1ll << 40) - 1;
 #endif
   __shared__ float tile[4][P_PASS_ENVS * 32];
@@ -154,6 +164,87 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
   }
 }
 
+#ifdef PROBE_LIB
+// ------------------------------------------------------------------------------------------------------------------
+// In-process entry points (C ABI, plain pointers). Nothing here is part of the env: measurement only.
+__global__ void k_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+#define TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_perr, sizeof g_perr, "%s: %s", #x, hipGetErrorString(e_)); return -3; } } while (0)
+static char g_perr[256] = "";
+extern "C" const char *w2a_probe_last_error(void) { return g_perr; }
+
+// float4 copy of `bytes` (read + write = 2 x bytes through the fabric), best of `reps`: GB/s of this box right now
+extern "C" int w2a_probe_copy(size_t bytes, int reps, float *gbs_out, void *stream) {
+  if (!gbs_out || bytes < (1u << 20) || reps <= 0) { snprintf(g_perr, sizeof g_perr, "w2a_probe_copy: bad argument"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  float4 *a = nullptr, *b = nullptr;
+  TRY(hipMalloc(&a, bytes)); TRY(hipMalloc(&b, bytes));
+  TRY(hipMemsetAsync(a, 0x3c, bytes, s));
+  hipEvent_t e0, e1; TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    TRY(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, s, a, b, bytes / 16);
+    TRY(hipEventRecord(e1, s)); TRY(hipEventSynchronize(e1));
+    float ms; TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  *gbs_out = (float)(2.0 * (double)bytes / (best * 1e-3) / 1e9);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+  return 0;
+}
+
+// The step's traffic without any env logic on the CALLER's tables and index pattern: X [T][rows_per_day][8] float4,
+// W [w_rows][16] float4, xrow / wrow [n] = feature row and coefficient row of every env (n a multiple of 256).
+// us_out[0..2] = microseconds per launch (back to back, best of `reps` runs of `iters` launches): streams only, gathers
+// only, both. Scratch (state words, outputs) is allocated and freed here.
+extern "C" int w2a_probe_step_pattern(const void *X, uint32_t rows_per_day, int32_t T, const void *W, const uint32_t *xrow,
+                                      const uint32_t *wrow, int64_t n, int reps, int iters, float *us_out, void *stream) {
+  if (!X || !W || !xrow || !wrow || !us_out || n <= 0 || (n & 255) || T <= 0 || reps <= 0 || iters <= 0) {
+    snprintf(g_perr, sizeof g_perr, "w2a_probe_step_pattern: bad argument (n must be a multiple of 256)");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  u3 *hot = nullptr, *stepc = nullptr; int32_t *act = nullptr; float *reward = nullptr, *obs = nullptr; uint8_t *done = nullptr;
+  TRY(hipMalloc(&hot, n * sizeof(u3))); TRY(hipMalloc(&stepc, n * sizeof(u3))); TRY(hipMalloc(&act, n * 4));
+  TRY(hipMalloc(&reward, n * 4)); TRY(hipMalloc(&done, n)); TRY(hipMalloc(&obs, n * 29 * 4));
+  TRY(hipMemsetAsync(hot, 0, n * sizeof(u3), s)); TRY(hipMemsetAsync(act, 0, n * 4, s));
+  TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rows_per_day), &rows_per_day, sizeof(rows_per_day), 0, hipMemcpyHostToDevice, s));
+  {  // stepc.b / .c carry the gather indices (PROBE_DEP: they reach the gathers through the streamed state, like the env's)
+    u3 *hs = (u3 *)malloc(n * sizeof(u3));
+    uint32_t *hx = (uint32_t *)malloc(n * 4), *hw = (uint32_t *)malloc(n * 4);
+    TRY(hipMemcpyAsync(hx, xrow, n * 4, hipMemcpyDeviceToHost, s)); TRY(hipMemcpyAsync(hw, wrow, n * 4, hipMemcpyDeviceToHost, s));
+    TRY(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i) { hs[i] = u3{}; hs[i].b = hx[i]; hs[i].c = hw[i]; }
+    TRY(hipMemcpyAsync(stepc, hs, n * sizeof(u3), hipMemcpyHostToDevice, s)); TRY(hipStreamSynchronize(s));
+    free(hs); free(hx); free(hw);
+  }
+  hipEvent_t e0, e1; TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+  const dim3 grid((unsigned)(n / 256)), block(256);
+  const float4 *Xp = (const float4 *)X, *Wp = (const float4 *)W;
+  for (int k = 0; k < 3; ++k) {
+    float best = 1e30f;
+    for (int rep = 0; rep < reps; ++rep) {
+      TRY(hipEventRecord(e0, s));
+      for (int it = 0; it < iters; ++it) {
+        const int64_t nn = ((int64_t)(it % T) << 40) | n;  // PROBE_DAYS: another day slice every launch
+        if (k == 0) hipLaunchKernelGGL((k_probe<true, false>), grid, block, 0, s, hot, stepc, act, hot, reward, done, obs, Wp, Xp, wrow, xrow, nn);
+        if (k == 1) hipLaunchKernelGGL((k_probe<false, true>), grid, block, 0, s, hot, stepc, act, hot, reward, done, obs, Wp, Xp, wrow, xrow, nn);
+        if (k == 2) hipLaunchKernelGGL((k_probe<true, true>), grid, block, 0, s, hot, stepc, act, hot, reward, done, obs, Wp, Xp, wrow, xrow, nn);
+      }
+      TRY(hipEventRecord(e1, s)); TRY(hipEventSynchronize(e1));
+      float ms; TRY(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) best = ms;
+    }
+    us_out[k] = best * 1e3f / (float)iters;
+  }
+  TRY(hipGetLastError());
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(hot); (void)hipFree(stepc); (void)hipFree(act); (void)hipFree(reward); (void)hipFree(done); (void)hipFree(obs);
+  return 0;
+}
+#else
 int main() {
   const int64_t n = 1 << 20;
   const int S = 74600, R = 8206;  // coefficient rows (x 256 B) and day-slice rows (x 128 B)
@@ -229,3 +320,4 @@ int main() {
   }
   return 0;
 }
+#endif  // PROBE_LIB

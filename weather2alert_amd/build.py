@@ -102,5 +102,31 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+PROBE_SRC = os.path.join(ROOT, "tools", "fabric_probe.hip")
+PROBE_LIB = os.path.join(LIB_DIR, "libw2a_probe.so")
+# the flag set of profiles/probe_ceiling.json: the step's fp64 chain, gather indices through the streamed state, another
+# day slice every launch, random data, state updated in place, the 16-B packed lock-step streams
+PROBE_FLAGS = ("-DPROBE_LIB", "-DPROBE_F64", "-DPROBE_DEP", "-DPROBE_DAYS", "-DPROBE_RANDOM_DATA", "-DPROBE_INPLACE")
+
+
+def build_probe_lib(force: bool = False, packed: bool = True) -> str:
+    """MEASUREMENT ONLY (not part of the env): tools/fabric_probe.hip as a shared library, so that bench.py can time the
+    arithmetic-free access pattern of the step and a plain float4 copy inside its own process, on its own box."""
+    out = PROBE_LIB if packed else PROBE_LIB.replace(".so", "_unpacked.so")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(PROBE_SRC):
+        return out
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = f"{out}.{os.getpid()}.tmp"
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *PROBE_FLAGS,
+           *(["-DPROBE_PACKED"] if packed else []), PROBE_SRC, "-o", tmp]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on the probe library ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_probe_lib(force="--force" in sys.argv))
+    print(build_probe_lib(force="--force" in sys.argv, packed=False))
