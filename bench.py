@@ -77,7 +77,7 @@ def parse(argv=None):
     p.add_argument("--no-extras", action="store_true",
                    help="skip the reported extras (always-alert policy, sorted episode order, posterior-mean reward)")
     p.add_argument("--no-calibration", action="store_true",
-                   help="skip the in-process copy-rate / access-pattern probe that precedes the warm-up steps")
+                   help="skip the in-process copy-rate / access-pattern probe that follows the timed region")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: the workload's env count per GPU (default); strong: that count split over the GPUs")
@@ -413,7 +413,7 @@ def box_calibration(env, dt, ct, packed, torch):
     from weather2alert_amd import build as wbuild
 
     out = {"source": "tools/fabric_probe.hip " + " ".join(wbuild.PROBE_FLAGS) + (" -DPROBE_PACKED" if packed else "") +
-                     ", in this process, on this run's tables and episode tuples, before the warm-up steps"}
+                     ", in this process, on this run's tables and episode tuples, right after the timed region"}
     try:
         lib = C.CDLL(wbuild.build_probe_lib(packed=packed))
         lib.w2a_probe_last_error.restype = C.c_char_p
@@ -421,10 +421,11 @@ def box_calibration(env, dt, ct, packed, torch):
         lib.w2a_probe_step_pattern.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
         stream = torch.cuda.current_stream().cuda_stream
-        gbs = C.c_float(0.0)
-        if lib.w2a_probe_copy(1 << 30, 5, C.byref(gbs), stream) != 0:
+        gbs = (C.c_float * 3)()
+        if lib.w2a_probe_copy(1 << 30, 5, gbs, stream) != 0:
             raise RuntimeError(lib.w2a_probe_last_error().decode())
-        out["copy_gbs"] = float(gbs.value)
+        out["copy_gbs"] = float(gbs[0])
+        out["copy_gbs_variants"] = {"float4_kernel_one_element_per_thread": float(gbs[1]), "hipMemcpyAsync_d2d": float(gbs[2])}
         st = env.state()
         xrow = (st["county_w"] * ct.Y + st["year_i"]).to(torch.int32).contiguous()
         wrow = (st["coef_col"] * ct.n_samples + st["sample"]).to(torch.int32).contiguous()
@@ -681,11 +682,6 @@ def main():
     env.reset(seed=args.seed)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
-    # this box's memory side, in this process, on this run's access pattern (reads the state once: right after a reset
-    # the canonical words are current, so the handle is left as it was)
-    will_pack = bool(env._lib.w2a_query(env._h, 1)) and env.step_kernel_name == "k_step64" and args.step_kernel != "unpacked" \
-        and env._host_auto
-    calib = None if args.no_calibration else box_calibration(env, dt, ct, will_pack, torch)
     T = ct.T
     stepno = 0
     coll_ev = []
@@ -812,6 +808,9 @@ def main():
     wall, dev_ms = timed_region(segments=True)
     wall = wdist.max_over_ranks(wall, device)
     stepno_head = stepno  # where the headline region ended (the extra region below moves on)
+    # the form of the per-env state the step kernel streamed in the measured launches (read NOW: later read-backs of
+    # the state bring the canonical words up to date)
+    packed = all(packed_seen) if packed_seen else env.packed_state
     # ---- multi-GPU: the same K steps once more WITHOUT the return all-gather: what the collective costs end to end
     no_coll = None
     if world > 1:
@@ -821,6 +820,11 @@ def main():
         use_gather = True
     status = env.check_status()
     mean_ret = float(gather.mean(env._final_return).item())
+    # This box's memory side, in this process, on this run's tables and CURRENT episode tuples: right AFTER the timed
+    # region. (Before it, the probe's ~50 ms of full-bandwidth work changed what a short window measures: the driver's
+    # 20 steps read 42.7 us per launch behind the probe against 35 us without it, profiles/r04/bench_driver_args_*.log
+    # -- the chip throttles for some milliseconds after a burst.)
+    calib = None if args.no_calibration else box_calibration(env, dt, ct, packed, torch)
     collective_ms = min(a.elapsed_time(b) for a, b in coll_ev) if coll_ev else None
 
     # step-kernel launch time, live: HIP events on the launch stream around back-to-back launches inside one
@@ -847,9 +851,6 @@ def main():
                 env.step(pool[0])  # finish this episode: the measurement must not contain a reset kernel
         kms, _ = timed_steps(env, pool, k_steps, torch)
         kernel_us = kms * 1e3 / k_steps
-    # the form of the per-env state the step kernel streamed in the measured launches
-    packed = all(packed_seen) if (segs and packed_seen) else env.packed_state
-
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
@@ -925,8 +926,9 @@ def main():
                                                       "kernel_avg_us", "src_sha", "commit", "profile")},
                          "traffic_note": traffic_note, "kernel_src_sha": src_sha,
                          "probe_ceiling": probe,
-                         # measured in THIS process on THIS box before the warm-up steps (box_calibration)
+                         # measured in THIS process on THIS box right after the timed region (box_calibration)
                          "copy_gbs_this_box": None if not calib else calib.get("copy_gbs"),
+                         "copy_gbs_variants_this_box": None if not calib else calib.get("copy_gbs_variants"),
                          "probe_us_this_box": None if not calib else calib.get("probe_us"),
                          "kernel_over_probe": (per_launch_s * 1e6 / calib["probe_us"]["streams_and_gathers"])
                          if calib and calib.get("probe_us") else None,

@@ -167,30 +167,41 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
 #ifdef PROBE_LIB
 // ------------------------------------------------------------------------------------------------------------------
 // In-process entry points (C ABI, plain pointers). Nothing here is part of the env: measurement only.
-__global__ void k_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// float4 copy, ONE 16-B element per thread and as many workgroups as that takes: of the forms tried on MI355X (grid-stride
+// loops of 1 024 .. 16 384 workgroups with 4 or 8 loads in flight, per-workgroup chunks, non-temporal stores,
+// hipMemcpyAsync: 4.4 .. 5.9 TB/s, profiles/r04/copy_explore.log) the only one that reaches the 6.2-6.3 TB/s
+// MI355X_MICROARCH.md quotes for "float4 copy"
+__global__ __launch_bounds__(256) void k_copy16(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 #define TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_perr, sizeof g_perr, "%s: %s", #x, hipGetErrorString(e_)); return -3; } } while (0)
 static char g_perr[256] = "";
 extern "C" const char *w2a_probe_last_error(void) { return g_perr; }
 
-// float4 copy of `bytes` (read + write = 2 x bytes through the fabric), best of `reps`: GB/s of this box right now
+// copy of `bytes` (read + write = 2 x bytes through the fabric), best of `reps` per variant: GB/s of this box right
+// now. gbs_out[0] = the best of gbs_out[1..2] = {float4 kernel, hipMemcpyAsync device-to-device}
 extern "C" int w2a_probe_copy(size_t bytes, int reps, float *gbs_out, void *stream) {
   if (!gbs_out || bytes < (1u << 20) || reps <= 0) { snprintf(g_perr, sizeof g_perr, "w2a_probe_copy: bad argument"); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  float4 *a = nullptr, *b = nullptr;
+  v4f *a = nullptr, *b = nullptr;
   TRY(hipMalloc(&a, bytes)); TRY(hipMalloc(&b, bytes));
   TRY(hipMemsetAsync(a, 0x3c, bytes, s));
   hipEvent_t e0, e1; TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int r = 0; r < reps + 1; ++r) {
-    TRY(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, s, a, b, bytes / 16);
-    TRY(hipEventRecord(e1, s)); TRY(hipEventSynchronize(e1));
-    float ms; TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (r > 0 && ms < best) best = ms;
+  gbs_out[0] = 0.0f;
+  for (int variant = 0; variant < 2; ++variant) {
+    float best = 1e30f;
+    for (int r = 0; r < reps + 1; ++r) {
+      TRY(hipEventRecord(e0, s));
+      if (variant == 0) hipLaunchKernelGGL(k_copy16, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, s, a, b, bytes / 16);
+      else TRY(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
+      TRY(hipEventRecord(e1, s)); TRY(hipEventSynchronize(e1));
+      float ms; TRY(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms < best) best = ms;
+    }
+    gbs_out[1 + variant] = (float)(2.0 * (double)bytes / (best * 1e-3) / 1e9);
+    if (gbs_out[1 + variant] > gbs_out[0]) gbs_out[0] = gbs_out[1 + variant];
   }
-  *gbs_out = (float)(2.0 * (double)bytes / (best * 1e-3) / 1e9);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
   return 0;
 }
