@@ -1,5 +1,7 @@
 """Host logic: table compiler (slot layout, day-major rows, weight rows, similar-county CSR)
 checked against the oracle's independent loader on the committed mini data set."""
+import os
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,103 @@ def test_slot_layout_is_data_driven():
     sd2.meta["exo_cols"] = sd2.meta["exo_cols"] + ["extra_feature"]
     with pytest.raises(tables.SchemaError):
         tables.compile_from_synth(sd2)
+
+
+def test_pandas_etl_file_format_compiles_to_the_same_tables(tmp_path):
+    """What pandas actually leaves on disk when the reference's ETL writes the 65k split
+    (data-processing/merge_state_actions.py:249-287: filtered frames -> a gapped integer index stored as
+    `__index_level_0__`; bool `alert`; int64 counters; `significance` with NaN for "no alert"; 14 years, 2006-2019 as in
+    data-processing/conf/config.yaml:8-9) must compile to exactly the tables of the plain in-memory layout -- and to the
+    tables compiled straight from the synthetic arrays. The real HF files cannot be fetched here; their format can."""
+    import pandas as pd
+    import pyarrow.parquet as pq
+
+    sd = synth.make_synth("linear", n_fips=9, years=list(range(2006, 2020)), n_samples=3, seed=8, extra_confounder_fips=2)
+    plain, etl = tmp_path / "plain", tmp_path / "etl"
+    synth.write_reference_files(sd, str(plain), "linear")
+    synth.write_reference_files(sd, str(etl), "linear", style="pandas_etl")
+    for name in ("exogenous_states", "endogenous_states_actions"):
+        cols = pq.read_schema(etl / "data" / "65k" / f"{name}.parquet").names
+        assert "__index_level_0__" in cols, (name, cols)  # the filtered frame's index really travelled in the file
+        assert "__index_level_0__" not in pq.read_schema(plain / "data" / "65k" / f"{name}.parquet").names
+    endo = pd.read_parquet(etl / "data" / "65k" / "endogenous_states_actions.parquet")
+    assert endo["alert"].dtype == bool and endo["remaining_budget"].dtype == np.int64 and endo["alert_streak"].dtype == np.int64
+    assert endo["significance"].isna().any() and not endo.index.equals(pd.RangeIndex(len(endo)))
+    a = tables.compile_from_files(str(plain), "linear")
+    b = tables.compile_from_files(str(etl), "linear")
+    c = tables.compile_from_synth(sd)
+    assert a.years == b.years == list(range(2006, 2020)) and a.Y == 14
+    for other in (b, c):
+        assert a.columns == other.columns and a.fips_weather == other.fips_weather and a.fips_list == other.fips_list
+        assert a.sig_categories == other.sig_categories and a.obs_slot == other.obs_slot and a.slot_of == other.slot_of
+        for k in tables.CompiledTables._ARRAYS:
+            np.testing.assert_array_equal(getattr(a, k), getattr(other, k), err_msg=k)
+    # the oracle's loader (the reference's own pandas calls, env.py:49-56) reads the same episodes from both layouts
+    ra, rb = O.RefData.from_files(str(plain), "linear"), O.RefData.from_files(str(etl), "linear")
+    assert ra.columns == rb.columns and ra.episodes.keys() == rb.episodes.keys()
+    for k in ra.episodes:
+        np.testing.assert_array_equal(ra.episodes[k], rb.episodes[k])
+
+
+def test_string_dtype_and_timestamp_columns_are_accepted(tmp_path):
+    """Frames whose text columns are not `object` (pyarrow-backed strings: the default of newer pandas) and whose `date`
+    is a real timestamp compile to the same tables."""
+    import pandas as pd
+
+    sd = synth.make_synth("linear", n_fips=5, years=[2006, 2007], n_samples=2, seed=3)
+    root = tmp_path / "r"
+    synth.write_reference_files(sd, str(root), "linear")
+    ref = tables.compile_from_files(str(root), "linear")
+    ddir = root / "data" / "65k"
+    for name in ("exogenous_states", "endogenous_states_actions"):
+        df = pd.read_parquet(ddir / f"{name}.parquet")
+        df["fips"] = df["fips"].astype("string[pyarrow]")
+        df["date"] = pd.to_datetime(df["date"])
+        if "significance" in df:
+            df["significance"] = df["significance"].astype("string[pyarrow]")
+        df.to_parquet(ddir / f"{name}.parquet")
+    got = tables.compile_from_files(str(root), "linear")
+    assert got.sig_categories == ref.sig_categories and got.fips_weather == ref.fips_weather
+    for k in tables.CompiledTables._ARRAYS:
+        np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=k)
+
+
+def test_missing_files_come_from_the_hub_like_the_reference(tmp_path, monkeypatch):
+    """resolve_artifact's fallback (tables.py): a file absent under data_dir is fetched with the very arguments the
+    reference passes to hf_hub_download (env.py:40-47: repo mauriciogtec/HeatAlertsRL-Data, repo_type "dataset",
+    subfolder "data/<split>"; env.py:60-67: repo mauriciogtec/HeatAlertsRL-Models, repo_type "model",
+    subfolder = weights; local_dir = data_dir). The hub itself is a stand-in (no network here) that serves from a
+    directory and records its calls."""
+    import shutil
+    import sys
+    import types
+
+    sd = synth.make_synth("linear", n_fips=6, years=[2006], n_samples=2, seed=5)
+    hub, local = tmp_path / "hub", tmp_path / "local"
+    synth.write_reference_files(sd, str(hub), "linear")
+    want = tables.compile_from_files(str(hub), "linear")
+    calls = []
+
+    def hf_hub_download(repo_id, filename, subfolder=None, repo_type=None, local_dir=None, **kw):
+        calls.append((repo_id, repo_type, subfolder, filename, local_dir))
+        dst = os.path.join(local_dir, subfolder, filename)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copy(os.path.join(str(hub), subfolder, filename), dst)
+        return dst
+
+    monkeypatch.setitem(sys.modules, "huggingface_hub", types.SimpleNamespace(hf_hub_download=hf_hub_download))
+    local.mkdir()
+    # one file is already there (a partial download): only the missing ones are fetched
+    os.makedirs(local / "data" / "65k")
+    shutil.copy(hub / "data" / "65k" / "confounders.parquet", local / "data" / "65k" / "confounders.parquet")
+    got = tables.compile_from_files(str(local), "linear")
+    for k in tables.CompiledTables._ARRAYS:
+        np.testing.assert_array_equal(getattr(got, k), getattr(want, k), err_msg=k)
+    assert sorted(calls) == sorted([
+        ("mauriciogtec/HeatAlertsRL-Data", "dataset", "data/65k", "exogenous_states.parquet", str(local)),
+        ("mauriciogtec/HeatAlertsRL-Data", "dataset", "data/65k", "endogenous_states_actions.parquet", str(local)),
+        ("mauriciogtec/HeatAlertsRL-Models", "model", "linear", "posterior_samples.safetensors", str(local)),
+        ("mauriciogtec/HeatAlertsRL-Models", "model", "linear", "config.yaml", str(local))])
+    calls.clear()
+    tables.compile_from_files(str(local), "linear")  # second time: everything is local, the hub is not asked
+    assert calls == []

@@ -346,13 +346,23 @@ def make_synth(
     )
 
 
-def write_reference_files(data: SynthData, root: str, weights: str = "linear", split: str = "65k") -> dict:
+def write_reference_files(data: SynthData, root: str, weights: str = "linear", split: str = "65k",
+                          style: str = "plain") -> dict:
     """Write ``data`` in the on-disk layout the reference downloads from the HF hub
     (env.py:40-47,60-67 with ``local_dir=root``):
 
         root/data/<split>/{exogenous_states,endogenous_states_actions,confounders}.parquet
         root/<weights>/{posterior_samples.safetensors,config.yaml}
-    """
+
+    style="plain": frames built in memory, default RangeIndex. style="pandas_etl": what pandas leaves behind when the
+    reference's ETL writes the 65k split (data-processing/merge_state_actions.py:249-287): the frames are FILTERED views
+    of the all-counties frame (`df[df.fips.isin(confounders_65k.fips)].to_parquet(...)`), so their integer index has gaps
+    and travels in the file as `__index_level_0__`; `alert` is bool (:118), `weekend` / `holiday` / `dos` /
+    `alert_lag1` / `alert_streak` / `remaining_budget` are int64 (:151,:158,:175,:183,:191,:196), `significance` is an
+    object column whose missing values are float NaN from the left merge (:116), stored as nulls; the yaml `fips_list` is
+    written unquoted where yaml allows it (weights/linear/config.yaml:16-28: `- 01073` stays a string only because of the
+    leading zero + 8/9 or the quotes yaml adds). The real files themselves are unreachable offline; this pins what
+    their FORMAT does to the table compiler."""
     import pandas as pd
     import yaml
     from safetensors.numpy import save_file
@@ -374,20 +384,43 @@ def write_reference_files(data: SynthData, root: str, weights: str = "linear", s
         exo[c] = v.astype(np.int64) if c in EXO_INT_COLS else v
     exo["fips"] = fips_col
     exo["date"] = date_col
-    pd.DataFrame(exo).to_parquet(os.path.join(ddir, "exogenous_states.parquet"))
-    sig = np.asarray([None] + list(SIGNIFICANCE_VALUES), dtype=object)[data.significance.reshape(-1)]
+    etl = style == "pandas_etl"
+    if style not in ("plain", "pandas_etl"):
+        raise ValueError(f"style {style!r}")
+
+    def save(frame: "pd.DataFrame", path: str):
+        if not etl:
+            frame.to_parquet(path)
+            return
+        # the all-counties frame holds counties the 65k confounders do not: two made-up ones interleaved here, then
+        # filtered away exactly like the ETL does -- the written frame keeps the surviving rows' original index
+        n0 = Y * T
+        extra = frame.iloc[:n0].copy()
+        parts = []
+        for k, fake in enumerate(("99001", "99003")):
+            e = extra.copy()
+            e["fips"] = fake
+            parts.append(e)
+        cut = (len(frame) // (2 * n0)) * n0
+        full = pd.concat([parts[0], frame.iloc[:cut], parts[1], frame.iloc[cut:]], ignore_index=True)
+        kept = full[full.fips.isin(set(data.fips_weather))]
+        assert len(kept) == len(frame) and not kept.index.equals(pd.RangeIndex(len(kept)))
+        kept.to_parquet(path)
+
+    save(pd.DataFrame(exo), os.path.join(ddir, "exogenous_states.parquet"))
+    sig = np.asarray([np.nan if etl else None] + list(SIGNIFICANCE_VALUES), dtype=object)[data.significance.reshape(-1)]
     endo = {
         "fips": fips_col,
         "date": date_col,
-        "alert": data.alert.reshape(-1),
+        "alert": data.alert.reshape(-1).astype(bool) if etl else data.alert.reshape(-1),
         "alerts_2wks": data.alerts_2wks.reshape(-1).astype(np.float64),
-        "alert_lag1": data.alert_lag1.reshape(-1),
-        "alert_streak": data.alert_streak.reshape(-1),
-        "remaining_budget": data.remaining_budget.reshape(-1),
+        "alert_lag1": data.alert_lag1.reshape(-1).astype(np.int64) if etl else data.alert_lag1.reshape(-1),
+        "alert_streak": data.alert_streak.reshape(-1).astype(np.int64) if etl else data.alert_streak.reshape(-1),
+        "remaining_budget": data.remaining_budget.reshape(-1).astype(np.int64) if etl else data.remaining_budget.reshape(-1),
         "issued_in_advance": data.issued_in_advance.reshape(-1).astype(np.float64),
         "significance": sig,
     }
-    pd.DataFrame(endo).to_parquet(os.path.join(ddir, "endogenous_states_actions.parquet"))
+    save(pd.DataFrame(endo), os.path.join(ddir, "endogenous_states_actions.parquet"))
     nconf = len(data.confounder_fips)
     crng = np.random.default_rng(12345)
     pd.DataFrame(

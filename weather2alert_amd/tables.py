@@ -253,6 +253,9 @@ def compile_from_files(data_dir: str | None, weights: str = "nn_full_medicare_al
         paths[file] = resolve_artifact(data_dir, weights, file, "mauriciogtec/HeatAlertsRL-Models", "model")
     merged = pd.merge(pd.read_parquet(paths["exogenous_states"]),
                       pd.read_parquet(paths["endogenous_states_actions"]), on=["fips", "date"])
+    if not pd.api.types.is_string_dtype(merged["date"]) and not merged["date"].dtype == object:
+        # the reference slices the string (env.py:54); a file that carries real timestamps is accepted as well
+        merged["date"] = pd.to_datetime(merged["date"]).dt.strftime("%Y-%m-%d")
     merged["year"] = merged.date.str[:4].astype(int)
     conf = pd.read_parquet(paths["confounders"])
     post = {}
@@ -274,12 +277,13 @@ def compile_from_files(data_dir: str | None, weights: str = "nn_full_medicare_al
     num = pd.DataFrame(index=merged.index)
     for c in columns:
         col = merged[c]
-        if col.dtype == object:
+        # text columns (object dtype with today's pandas, a string dtype with pandas >= 3 / pyarrow-backed frames)
+        if not (pd.api.types.is_numeric_dtype(col) or pd.api.types.is_bool_dtype(col)):
             cc = sorted(x for x in col.dropna().unique())
             if c == "significance":
                 cats = [str(x) for x in cc]
             lut = {v: float(i + 1) for i, v in enumerate(cc)}
-            num[c] = col.map(lambda v: 0.0 if v is None or v != v else lut[v]).astype(np.float64)
+            num[c] = col.map(lambda v: 0.0 if (v is None or v is pd.NA or v != v) else lut[v]).astype(np.float64)
         else:
             num[c] = col.astype(np.float64)
     vals64 = num[columns].values
