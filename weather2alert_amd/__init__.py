@@ -8,14 +8,22 @@ them raises. There is no CPU fallback.
 """
 __version__ = "0.1.0"
 
-__all__ = ["HeatAlertEnv", "HeatAlertVecEnv", "CompiledTables", "compile_from_files", "compile_from_synth"]
+__all__ = ["HeatAlertEnv", "HeatAlertVecEnv", "KernelOptions", "CompiledTables", "compile_from_files", "compile_from_synth"]
 
 
 def __getattr__(name):
-    if name in ("HeatAlertEnv", "HeatAlertVecEnv"):
-        from . import env
+    if name == "HeatAlertVecEnv":
+        from .env import HeatAlertVecEnv
 
-        return getattr(env, name)
+        return HeatAlertVecEnv
+    if name == "HeatAlertEnv":
+        from .dropin import HeatAlertEnv
+
+        return HeatAlertEnv
+    if name == "KernelOptions":
+        from .options import KernelOptions
+
+        return KernelOptions
     if name in ("CompiledTables", "compile_from_files", "compile_from_synth", "DeviceTables"):
         from . import tables
 

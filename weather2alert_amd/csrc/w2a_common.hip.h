@@ -252,21 +252,14 @@ __device__ __forceinline__ float sigmoid_f32(float z) {
   return __builtin_amdgcn_rcpf(1.0f + e);    // v_rcp_f32 (1 ulp); rcp(+inf) = 0
 }
 
-#ifndef W2A_F64_SIGMOID
-#define W2A_F64_SIGMOID 0  // A/B: float64 sigmoid + reward instead of the f32 v_exp/v_rcp form
-#endif
-// env.py:211-221 from the two float64 logits. float64 form: expit in double up to libm rounding;
+// env.py:211-221 from the two float64 logits: f32 sigmoids (v_exp_f32 / v_rcp_f32) and reward. The reference's epilogue is
+// float64 expit; against it this form measures <= 1.1e-6 on the reward (bar 1e-5; a float64 exp / divide build variant
+// existed until round 3 -- +13 % kernel time for 2.4e-7 -- and was removed untested rather than kept unexercised).
 // exp(-z) -> +inf gives exactly 0 (closed gate: ze = -inf).
 __device__ __forceinline__ float reward_from_logits(double zb, double ze, uint32_t actual) {
-#if W2A_F64_SIGMOID
-  const double base = 1.0 / (1.0 + exp(-zb));
-  const double eff = 1.0 / (1.0 + exp(-ze));
-  return (float)(-1000.0 / 152.0 * base * (1.0 - eff * (double)actual));
-#else
   const float base = sigmoid_f32((float)zb);
   const float eff = sigmoid_f32((float)ze);
   return -(1000.0f / 152.0f) * base * (1.0f - eff * (float)actual);
-#endif
 }
 
 // ----------------------------------------------------------------------------------------

@@ -41,14 +41,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     if (s && hipStreamIsCapturing(s, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
     else (void)hipGetLastError();
   }
-#if W2A_F64_SIGMOID
-  if (given) return fail(W2A_ERR_ARG, "w2a_step: W2A_STEP_REWARD_GIVEN is not built into a W2A_F64_SIGMOID library");
-  const bool wide = false;
-#else
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = (given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS) && !(flags & W2A_STEP_CLASSIC);
-#endif
   // which kernel, on which form of the per-env state; the form conversions (k_pack_state / k_unpack_state) are launched
   // from inside, and the day every env is on after this call is recorded there
   HipDev dv{env, s};
@@ -56,7 +51,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (plan.kernel < 0)
     return fail(W2A_ERR_STATE, "w2a_step: stream capture started while the step state is in its packed lock-step form; "
                                "call w2a_get_state (or any entry point that reads the canonical state) before capturing");
-#if !W2A_F64_SIGMOID
   if (plan.kernel != W2A_BK_STEP_CLASSIC) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
@@ -95,7 +89,6 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     HIP_TRY(hipGetLastError());
     return W2A_OK;
   }
-#endif
 #define W2A_LAUNCH(AR, OB) \
   do { if (env->tb.fixes) hipLaunchKernelGGL((k_step<AR, OB, true>), grid, block, 0, s, a); \
        else hipLaunchKernelGGL((k_step<AR, OB, false>), grid, block, 0, s, a); } while (0)

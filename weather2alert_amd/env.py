@@ -12,13 +12,14 @@ fallback -- constructing an env without a ROCm device or without libw2a.so raise
 from __future__ import annotations
 
 import ctypes as C
-from collections.abc import Mapping, Sequence
 from typing import Literal
 
 import numpy as np
 import torch
 
-from . import _ffi
+from . import _ffi, stats as _stats
+from .info import _LazyInfo
+from .options import KernelOptions
 from .rng import numpy_parity_episode
 from .spaces import Box, Discrete
 from .tables import CompiledTables, DeviceTables, compile_from_files
@@ -70,9 +71,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          its next episode and returns that episode's first observation with reward 0 and done =
                          False. Per env the sequence of episodes is the same as with "same_step" (device seed mode
                          only).
-    reward_path          "gather" (or "auto"): each step gathers the env's coefficient rows and sums the 28 terms. The
-                         precomputed logit-table path of round 1 ("table") was removed: it was slower at every batch
-                         size (each 16-B logit pair dragged a cold 128-B line of a 2 GB table).
     episode_order        "iid" (default): env i keeps its own independent draws, like N reference envs;
                          "sorted": after every (lock-step) reset the envs are relabelled so that env indices
                          follow the coefficient row. The batch holds exactly the same multiset of
@@ -91,35 +89,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          alert_lag1 is yesterday's action), "penalty" (Q5: -1 for an alert attempted at budget),
                          "obs" (Q6: step() returns the next day's row), "augment" (Q8: the drawn similar county
                          supplies weather and coefficients), "budget" (Q9: per-episode budgets, no stickiness).
-    rollout_order        True (default): rollout() lets the kernel visit the envs in the order of their feature rows
-                         (w2a_rollout_order, one sort per episode); outputs are indexed by env id either way.
-    rollout_mfma         True (default): with that order, a batch in lock step and faithful semantics rollout() computes
-                         the 27 action-independent terms of both logits for all envs of a (county, year) and 16 days at a
-                         time on the int8 matrix cores (exact fixed-point digits, csrc/w2a_rollout_mfma.hip.h) and only
-                         the 3 run-time terms per day in fp64. Integers identical, returns within ~1e-6 relative.
     reward_mode          "sampled" (default, the reference: one posterior draw per episode, env.py:160,209,216) or
                          "posterior_mean": every step's reward is the mean over ALL posterior draws of the env's
                          coefficient column -- the legacy env's eval mode (_deprecated/env.py:332-342) on today's
                          reward form -- one grouped contraction per step (csrc/w2a_posterior.hip.h).
                          Needs lock-step / disabled autoreset and faithful semantics.
-    pm_kernel            which kernel computes that contraction: "vector" (fp64 FMAs on the vector ALU with
-                         DPP-broadcast coefficients), "matrix" (fp64 matrix cores, v_mfma_f64_16x16x4_f64),
-                         "matrix_i8" (int8 matrix cores on exact fixed-point digits of both operands,
-                         v_mfma_i32_16x16x64_i8 with int32 accumulation; csrc/w2a_posterior_i8.hip.h; the DEFAULT: the
-                         fastest of the three on MI355X, and a fixed choice keeps rewards bit-reproducible from run
-                         to run and from rank to rank), or "auto" (opt-in): all are timed once on this env's own batch
-                         after the first reset and the fastest one is kept (``pm_kernel_choice`` /
-                         ``pm_kernel_timing_us`` say which and why). The kernels agree to ~1e-7, not to the last bit,
-                         so "auto" gives up bit reproducibility between runs; within one torch.distributed job rank
-                         0's choice is broadcast, so every shard computes with the same kernel, and a checkpoint
-                         carries the choice, so a resumed run continues on it.
-    step_kernel          "auto" (default): batches of >= 131 072 envs with faithful semantics run the 64-envs-per-wave
-                         kernel (csrc/w2a_step64.hip.h; in-kernel autoreset included), everything else the
-                         4-lanes-per-env kernel (the faster choice on MI355X at each size); "classic" / "wide" force one of them (same
-                         results up to the order of the fp64 additions; for A/B measurements and tests). While the
-                         batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env
-                         state instead of the 24-B canonical words (include/w2a.h, w2a_state_bytes; identical
-                         results; ``packed_state`` says whether it is in use); "unpacked" = "auto" without it.
+    kernel               KernelOptions (weather2alert_amd/options.py): the switches that select HOW a step, a rollout
+                         or the posterior-mean reward is computed -- step_kernel, write_obs, rollout_order, rollout_mfma,
+                         pm_kernel, reward_path -- never what; each may also be passed by name (step_kernel="wide", ...).
+                         Every combination gives the same results up to the order of the fp64 additions (~1e-7 for
+                         the posterior-mean kernels); the defaults are the fastest choice on MI355X.
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -144,18 +123,18 @@ class HeatAlertVecEnv(_VectorEnvBase):
         autoreset: Literal["same_step", "next_step", "disabled"] = "same_step",
         tables: CompiledTables | DeviceTables | None = None,
         env_gid0: int = 0,
-        write_obs: bool = True,
-        reward_path: Literal["gather", "table", "auto"] = "gather",
         episode_order: Literal["iid", "sorted"] = "iid",
         lockstep: bool | None = None,
         faithful: bool = True,
         fixes: set | list | None = None,
-        step_kernel: Literal["auto", "classic", "wide", "unpacked"] = "auto",
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
-        rollout_order: bool = True,
-        pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "matrix_i8",
-        rollout_mfma: bool = True,
+        kernel: KernelOptions | None = None,
+        **kernel_overrides,  # any field of KernelOptions by name (step_kernel=..., pm_kernel=..., write_obs=..., ...)
     ):
+        # HOW things are computed (never what): one record, weather2alert_amd/options.py
+        self.kernel = (kernel or KernelOptions()).with_overrides(**kernel_overrides)
+        write_obs, step_kernel, pm_kernel = self.kernel.write_obs, self.kernel.step_kernel, self.kernel.pm_kernel
+        rollout_order, rollout_mfma = self.kernel.rollout_order, self.kernel.rollout_mfma
         self._lib = _ffi.load()
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -185,27 +164,18 @@ class HeatAlertVecEnv(_VectorEnvBase):
         else:
             ct = tables if tables is not None else compile_from_files(data_dir, weights, split, years)
             self.dtables = DeviceTables(ct, self.device)
-        if reward_path == "table":
-            raise ValueError("reward_path='table' (the precomputed logit table of round 1) was removed: it was slower "
-                             "than the row-gather kernels at every batch size; use 'gather'")
-        if reward_path not in ("gather", "auto"):
-            raise ValueError(f"reward_path {reward_path!r}")
         reward_path = "gather"
         allf = set(_ffi.FIX_BITS) | {"budget"}
         self.fixes = set(allf) if (not faithful and fixes is None) else set(fixes or ())
         if self.fixes - allf:
             raise ValueError(f"unknown fixes {sorted(self.fixes - allf)}; choose from {sorted(allf)}")
         self.reward_path = reward_path
-        if step_kernel not in ("auto", "classic", "wide", "unpacked"):
-            raise ValueError(f"step_kernel {step_kernel!r}")
         self.step_kernel = step_kernel
         if reward_mode not in ("sampled", "posterior_mean"):
             raise ValueError(f"reward_mode {reward_mode!r}")
         if reward_mode == "posterior_mean" and (self.fixes or step_kernel == "classic"):
             raise ValueError("reward_mode='posterior_mean' needs faithful semantics and the 64-envs-per-wave step kernel")
         self.reward_mode = reward_mode
-        if pm_kernel not in ("auto", "vector", "matrix", "matrix_i8"):
-            raise ValueError(f"pm_kernel {pm_kernel!r}")
         self.pm_kernel = pm_kernel
         self.pm_kernel_choice = None if pm_kernel == "auto" else pm_kernel  # decided after the first reset
         self.pm_kernel_timing_us: dict = {}
@@ -863,144 +833,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._keep_act = act
         return steps
 
-    @classmethod
-    def episode_stats(cls, out: dict) -> dict:
-        """Batch summary of finished rollouts: mean return, alerts per episode, alerts attempted over budget per
-        episode, the histogram of alert days (needs rollout(..., alert_mask=True)) and, for whole-episode rollouts
-        with alert_mask=True, everything the reference's logging callback reports (callback_stats: same keys and
-        definitions as callbacks.py:61-77)."""
-        s = {"mean_return": float(out["return"].double().mean()),
-             "mean_alerts": float(out["alerts"].double().mean()),
-             "mean_attempts_over_budget": float(out["attempts_over_budget"].double().mean())}
-        if "alert_days" in out:
-            s["alert_day_hist"] = out["alert_days"].sum(0).cpu()
-            if bool(out["done"].all()) and bool((out["first_day"] == 0).all()):
-                s.update(cls.callback_stats(out))
-        return s
-
-    @staticmethod
-    def callback_stats(out: dict) -> dict:
-        """What the reference's AlertLoggingCallback logs at the end of a rollout (callbacks.py:61-77), computed on
-        the device from whole-episode rollout outputs (rollout(policy, alert_mask=True) from day 0): same keys, same
-        definitions. The callback polls attributes of the legacy env; they map to the current env as listed in
-        oracle/heatalert_oracle.py (attempted_alert_buffer, actual_alert_buffer for allowed_alert_buffer, "alert
-        attempted at budget" for penalize, the running return for cum_reward). Definitions that follow from its code:
-        streaks and alert days are those of ATTEMPTED alerts (:38-46), a streak is recorded when a no-alert day ends
-        it (an open streak at the end of the window is dropped), alert days are env.t after the step
-        (min(day + 1, n_days - 1)), the 50/80/100 % marks are the first index of the granted-alert list whose
-        cumulative fraction reaches the mark, read when env.t == n_days - 2 (:47-57), as is the logged reward."""
-        att, act = out["attempt_days"], out["alert_days"]
-        n, T = att.shape
-        nd = out["n_days"].long()
-        day = torch.arange(T, device=att.device)
-        live = day[None, :] < nd[:, None]
-        att, act = att & live, act & live
-        num_steps = int(nd.sum())
-        s = {"training_rewards": float(out["return_snapshot"].double().nan_to_num(0.0).mean()),
-             "over_budget_freq": float(out["attempts_over_budget"].sum()) / num_steps,
-             "alerts_freq": float(att.sum()) / num_steps}
-        t_after = torch.minimum(day[None, :] + 1, nd[:, None] - 1).double()
-        w = t_after[att]
-        s["average_t_alerts"] = float(w.mean()) if w.numel() else 0
-        s["stdev_t_alerts"] = float(w.std(unbiased=False)) if w.numel() else 0
-        # streaks of attempted alerts that a no-alert day ended inside the episode: run length at the day before
-        a = att.to(torch.int32)
-        c = a.cumsum(1)
-        zero_c = torch.where(a == 0, c, torch.zeros_like(c)).cummax(1).values  # cumsum at the last 0 so far
-        run = c - zero_c  # consecutive alerts ending at each day
-        ended = (a[:, 1:] == 0) & (a[:, :-1] == 1) & live[:, 1:]
-        lens = run[:, :-1][ended].double()
-        s["average_streak"] = float(lens.mean()) if lens.numel() else 0
-        s["stdev_streak"] = float(lens.std(unbiased=False)) if lens.numel() else 0
-        # 50 / 80 / 100 % marks over the granted alerts of days 0 .. n_days-3 (the list when t == n_days - 2)
-        seen = day[None, :] < (nd[:, None] - 2)
-        g = (act & seen).to(torch.int64)
-        cg = g.cumsum(1)
-        tot = cg[:, -1:]
-        has = tot[:, 0] > 0
-        frac = cg.double() / tot.clamp(min=1).double()
-        for key, q in (("alert_t_50%", 0.5), ("alert_t_80%", 0.8), ("alert_t_100%", 1.0)):
-            hit = ((frac == 1.0) if q == 1.0 else (frac >= q)) & seen
-            first = torch.where(hit, day[None, :], torch.full_like(cg, T)).min(1).values
-            s[key] = float(first[has].double().mean()) if bool(has.any()) else float("nan")
-        return s
-
-    CSV_FIELDS = ("year", "alert_budget", "sum_alerts", "reward", "average_t_alerts", "stdev_t_alerts",
-                  "average_streak", "stdev_streak", "alerts")  # callbacks.py:136-146
-
-    @staticmethod
-    def episode_rows(out: dict, chunk: int = 65536) -> list[dict]:
-        """One row per env in the format of the reference's FinalEvalCallback (callbacks.py:116-146) from whole-episode
-        rollout outputs: year, alert_budget, sum_alerts and reward as read when env.t == n_days - 2 (:128-132), alert
-        day / streak statistics over the GRANTED alerts of the whole episode (:118-126), and the granted-alert list.
-        Every statistic is computed on the device from the day bitmaps (the same run-length formulation as
-        callback_stats, per env instead of pooled); the host only formats the rows. The envs are processed `chunk` at a
-        time: the [chunk, T] intermediates stay at ~100 MB however large the batch is."""
-        n = out["alert_days"].shape[0]
-        rows: list[dict] = []
-        for lo in range(0, n, chunk):
-            hi = min(n, lo + chunk)
-            rows.extend(HeatAlertVecEnv._episode_rows_chunk({k: out[k][lo:hi] for k in (
-                "alert_days", "n_days", "year", "budget", "return_snapshot")}))
-        return rows
-
-    @staticmethod
-    def _episode_rows_chunk(out: dict) -> list[dict]:
-        act = out["alert_days"]
-        n, T = act.shape
-        dev = act.device
-        nd = out["n_days"].long()
-        day = torch.arange(T, device=dev)
-        live = day[None, :] < nd[:, None]
-        a = (act & live).to(torch.int32)  # counts <= T <= 1023: exact in int32 and in float64 below
-        cnt = a.sum(1)
-        # day of each granted alert as the callback sees it: env.t after the step = min(day + 1, n_days - 1)
-        t_after = torch.minimum(day[None, :] + 1, nd[:, None] - 1).double()
-        af = a.double()
-        c = cnt.clamp(min=1).double()
-        mean_t = (t_after * af).sum(1) / c
-        std_t = (((t_after - mean_t[:, None]) ** 2) * af).sum(1).div(c).sqrt()
-        del t_after, af
-        # streaks of granted alerts ended by a no-alert day inside the episode: run length at the day before
-        cs = a.cumsum(1, dtype=torch.int32)
-        zero_c = torch.where(a == 0, cs, torch.zeros_like(cs)).cummax(1).values
-        run = (cs - zero_c)[:, :-1].double()
-        ended = ((a[:, 1:] == 0) & (a[:, :-1] == 1) & live[:, 1:]).double()
-        del cs, zero_c
-        ns = ended.sum(1)
-        cn = ns.clamp(min=1.0)
-        mean_s = (run * ended).sum(1) / cn
-        std_s = (((run - mean_s[:, None]) ** 2) * ended).sum(1).div(cn).sqrt()
-        del run, ended
-        seen = (day[None, :] < (nd[:, None] - 2)).to(torch.int32)
-        sum_alerts = (a * seen).sum(1)
-        h = {k: v.cpu().numpy() for k, v in dict(
-            act=a.to(torch.uint8), nd=nd, year=out["year"], bud=out["budget"], snap=out["return_snapshot"], cnt=cnt,
-            mean_t=mean_t, std_t=std_t, ns=ns, mean_s=mean_s, std_s=std_s, sum_alerts=sum_alerts).items()}
-        rows = []
-        for i in range(n):
-            read = h["nd"][i] >= 3  # the callback only fills these when it sees t == n_days - 2
-            has_t, has_s = h["cnt"][i] > 0, h["ns"][i] > 0
-            rows.append({
-                "year": int(h["year"][i]) if read else 0, "alert_budget": int(h["bud"][i]) if read else 0,
-                "sum_alerts": int(h["sum_alerts"][i]) if read else 0, "reward": float(h["snap"][i]) if read else 0,
-                "average_t_alerts": float(h["mean_t"][i]) if has_t else 0,
-                "stdev_t_alerts": float(h["std_t"][i]) if has_t else 0,
-                "average_streak": float(h["mean_s"][i]) if has_s else 0,
-                "stdev_streak": float(h["std_s"][i]) if has_s else 0,
-                "alerts": h["act"][i, : h["nd"][i]].tolist() if read else []})
-        return rows
-
-    @classmethod
-    def write_episode_csv(cls, path: str, out: dict) -> None:
-        """The per-episode CSV of the reference's FinalEvalCallback (callbacks.py:151-157): header = its field names."""
-        import csv
-
-        with open(path, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(cls.CSV_FIELDS))
-            w.writeheader()
-            for row in cls.episode_rows(out):
-                w.writerow(row)
+    # ------------------------------------------------------------------ statistics (weather2alert_amd/stats.py)
+    episode_stats = staticmethod(_stats.episode_stats)
+    callback_stats = staticmethod(_stats.callback_stats)
+    episode_rows = staticmethod(_stats.episode_rows)
+    write_episode_csv = staticmethod(_stats.write_episode_csv)
+    CSV_FIELDS = _stats.CSV_FIELDS
 
     def _coerce_actions(self, actions):
         if not torch.is_tensor(actions):
@@ -1017,184 +855,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
         return _LazyInfo(self)
 
 
-class _LazyStrings(Sequence):
-    """The reference's per-env string entries of info (env.py:229-236) built on demand: element i is formatted
-    when it is asked for, so iterating over an info mapping of a million envs does not build a million strings."""
+def __getattr__(name):  # weather2alert_amd.env.HeatAlertEnv: the drop-in lives in dropin.py (it builds on this module)
+    if name == "HeatAlertEnv":
+        from .dropin import HeatAlertEnv
 
-    def __init__(self, n: int, fn):
-        self._n, self._fn = int(n), fn
-
-    def __len__(self):
-        return self._n
-
-    def __getitem__(self, i):
-        if isinstance(i, slice):
-            return [self._fn(j) for j in range(*i.indices(self._n))]
-        i = int(i)
-        if i < 0:
-            i += self._n
-        if not 0 <= i < self._n:
-            raise IndexError(i)
-        return self._fn(i)
-
-    def __eq__(self, other):
-        try:
-            return len(other) == self._n and all(a == b for a, b in zip(self, other))
-        except TypeError:
-            return NotImplemented
-
-    def __repr__(self):
-        head = ", ".join(repr(self[i]) for i in range(min(self._n, 3)))
-        return f"<{self._n} strings: {head}{', ...' if self._n > 3 else ''}>"
-
-
-class _LazyInfo(Mapping):
-    """info mapping whose entries are fetched from the device on first access (env.py:228-236); it shows the env's
-    state at that moment. Device tensors: remaining_budget, at_budget, location_index (coefficient column),
-    county_w, year, final_return, t; host values: feature_names, and the reference's string entries episode_index
-    ("<fips>_<year>") and location (env.py:118: under augmentation the fips at the drawn position of the filtered
-    similar-county list) as lazy sequences of num_envs strings. A real Mapping: get(), values(), items(), `in`
-    and len() all agree with iteration."""
-
-    _KEYS = ("remaining_budget", "at_budget", "location_index", "county_w", "year", "feature_names",
-             "final_return", "t", "episode_index", "location")
-    _HOST_KEYS = ("episode_index", "location")
-
-    def __init__(self, env: HeatAlertVecEnv):
-        self._env = env
-        self._d: dict = {}
-        self._np: dict = {}
-
-    def _fill(self):
-        if not self._d:
-            e = self._env
-            st = e.state()
-            years = torch.as_tensor(e.ct.years, dtype=torch.int32, device=e.device)
-            self._d.update(
-                remaining_budget=st["budget"] - st["used"], at_budget=st["at_budget"].bool(),
-                location_index=st["coef_col"], county_w=st["county_w"], year=years[st["year_i"].long()],
-                feature_names=e.feature_names, final_return=e._final_return, t=st["t"])
-
-    def _host_arr(self, k):
-        if k not in self._np:
-            self._np[k] = self._d[k].cpu().numpy()
-        return self._np[k]
-
-    def _host(self, k):
-        e, ct, n = self._env, self._env.ct, self._env.num_envs
-        if k == "episode_index":
-            return _LazyStrings(n, lambda i: f"{ct.fips_weather[self._host_arr('county_w')[i]]}_"
-                                             f"{self._host_arr('year')[i]}")
-        if e.seed_mode == "numpy_parity" and getattr(e, "_info_location", None):
-            loc = list(e._info_location)
-            return _LazyStrings(n, lambda i: loc[i])
-        # device-RNG episodes: whether the last reset augmented is a property of the reset call
-        aug = bool(e._reset_cfg[2]) if e._reset_cfg is not None else False
-        if not aug or "augment" in e.fixes:
-            return _LazyStrings(n, lambda i: ct.fips_list[self._host_arr("location_index")[i]])
-
-        def drawn(i):  # position li of the filtered similar list of the requested county (Q8)
-            sl = ct.similar_list(ct.fips_index(ct.fips_weather[self._host_arr("county_w")[i]]))
-            return ct.fips_list[int(sl[self._host_arr("location_index")[i]])]
-
-        return _LazyStrings(n, drawn)
-
-    def __getitem__(self, k):
-        if k not in self._KEYS:
-            raise KeyError(k)
-        self._fill()
-        if k in self._HOST_KEYS and k not in self._d:
-            self._d[k] = self._host(k)
-        return self._d[k]
-
-    def __iter__(self):
-        return iter(self._KEYS)
-
-    def __len__(self):
-        return len(self._KEYS)
-
-
-class HeatAlertEnv:
-    """Drop-in for ``weather2alert.env.HeatAlertEnv`` (env.py:17-262): same constructor,
-    ``reset(location, similar_climate_counties, seed, budget, sample_budget, sample_budget_type)``
-    and ``step(action) -> (obs, reward, done, False, info)``; one env on the GPU, episode draws
-    replayed from NumPy's Generator so identical seeds give identical episodes.
-
-    Differences by construction: observations are float32 arrays of the true width 29 with
-    ``alert`` as 0/1 and ``significance`` as a category code (the reference returns an object
-    array mixing floats, ints, bools and strings)."""
-
-    def __init__(self, weights: str = "nn_full_medicare_all", years: list | None = None,
-                 fips_list: list | None = None, similar_climate_counties: bool = False, budget: int | None = None,
-                 data_dir: str | None = None, split: str = "65k", device: str = "cuda:0",
-                 tables: CompiledTables | DeviceTables | None = None):
-        self._v = HeatAlertVecEnv(1, weights, years, fips_list, similar_climate_counties, budget, data_dir, split,
-                                  device, seed_mode="numpy_parity", autoreset="disabled", tables=tables)
-        ct = self._v.ct
-        self.fips_list, self.valid_years, self.n_samples = ct.fips_list, ct.years, ct.n_samples
-        self.similar_climate_counties = similar_climate_counties
-        self.observation_space = self._v.single_observation_space
-        self.action_space = self._v.single_action_space
-        self.feat_names = ct.feature_names
-        self._act = torch.zeros(1, dtype=torch.int32, device=self._v.device)
-
-    @property
-    def budget(self):
-        return self._v._sticky[0]
-
-    def _sync_state(self):
-        """One device-to-host copy per call: observation, reward, done, the status word and every decoded state
-        field are concatenated on the device (the reference's API returns Python scalars, so each call must
-        synchronise once -- but only once)."""
-        v = self._v
-        buf, _ = v._state_packed()
-        pack = torch.cat([v._obs.view(torch.int32).reshape(-1), v._reward.view(torch.int32),
-                          v._done.to(torch.int32), v._status, buf.reshape(-1)])
-        host = pack.cpu().numpy()
-        n_obs = v.ct.n_obs
-        self._h_obs = host[:n_obs].view(np.float32).copy()
-        self._h_reward = float(host[n_obs: n_obs + 1].view(np.float32)[0])
-        self._h_done = bool(host[n_obs + 1])
-        bits = int(host[n_obs + 2])
-        if bits:  # rare: let check_status() read-and-clear the word and raise what the reference raises
-            v.check_status()
-        fields = host[n_obs + 3:]
-        st = {k: fields[i] for i, k in enumerate(_ffi.STATE_FIELDS)}
-        ct = v.ct
-        self.t = int(st["t"])
-        self.alert_streak = int(st["streak"])
-        self.coef_index = int(st["sample"])
-        self.location_index = int(st["coef_col"])
-        self.remaining_budget = int(st["budget"] - st["used"])
-        self.at_budget = bool(st["at_budget"])
-        self.n_days = int(st["n_days"])
-        self.location = v._info_location[0]
-        self.ep_index = ct.fips_weather[int(st["county_w"])] + "_" + str(ct.years[int(st["year_i"])])
-        return st
-
-    def _get_info(self):
-        return {"episode_index": self.ep_index, "remaining_budget": self.remaining_budget,
-                "at_budget": self.at_budget, "feature_names": self.feat_names, "location": self.location,
-                "location_index": self.location_index}
-
-    def reset(self, location: str | None = None, similar_climate_counties: bool | None = None,
-              seed: int | None = None, budget: int | None = None, sample_budget: bool = False,
-              sample_budget_type: Literal["less_than", "centered"] = "less_than"):
-        if seed is None:
-            seed = np.random.randint(0, 10000)
-        obs, _ = self._v.reset(seed=[seed], options=dict(
-            location=location, similar_climate_counties=similar_climate_counties, budget=budget,
-            sample_budget=sample_budget, sample_budget_type=sample_budget_type))
-        self._sync_state()
-        self.observation = self._h_obs
-        return self.observation, self._get_info()
-
-    def step(self, action: int):
-        self._act.fill_(int(action))
-        self._v.step(self._act)
-        self._sync_state()
-        self.observation = self._h_obs
-        return self.observation, self._h_reward, self._h_done, False, self._get_info()
-
-    def close(self):
-        self._v.close()
+        return HeatAlertEnv
+    raise AttributeError(name)
