@@ -68,3 +68,72 @@ def test_policy_loop_over_a_ragged_batch_raises_no_status_bit():
         out = env.rollout(dict(kind="bernoulli", p=0.3, seed=5), alert_mask=True)
         assert bool(out["done"].all()) and env.check_status() == 0, pmk
         env.close()
+
+
+def test_dropin_env_random_call_sequences():
+    """The num_envs = 1 drop-in (`HeatAlertEnv`, NumPy-seed parity) under random interleavings of reset(**kwargs) and
+    step() against the scalar `OracleEnv` -- the line-by-line restatement of env.py:107-262 that is pinned bit-exact to
+    the reference's own trajectories: resets in the middle of an episode, steps after `done` (the reference keeps
+    recomputing the last day, env.py:256-262), every reset kwarg incl. seed=None (the global NumPy RNG, env.py:143-144),
+    the sticky budget through sample_budget of both types (Q9), augmentation (Q8), ragged episode lengths. The golden
+    tests replay reset + 153 steps; this is what the reference's API allows beyond that."""
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd import HeatAlertEnv, synth, tables
+    from weather2alert_amd.tables import DeviceTables
+
+    dev = torch.device("cuda:0")
+    worst, n_ops, n_after_done = 0.0, 0, 0
+    for variant in range(3):
+        sd = synth.make_synth("linear", n_fips=10 + variant, years=[2006, 2007, 2008][: 1 + variant], n_samples=4,
+                              n_days=[7, 12, 30][variant], seed=40 + variant, extra_confounder_fips=2)
+        if variant == 1:
+            sd.meta["n_days_per_episode"] = np.random.default_rng(5).integers(5, 13, size=(len(sd.fips_weather), len(sd.years)))
+        rd = O.RefData.from_synth(sd)
+        dt = DeviceTables(tables.compile_from_synth(sd), dev)
+        for seq in range(25):
+            rng = np.random.default_rng([variant, seq])
+            ctor = dict(similar_climate_counties=bool(rng.random() < 0.4),
+                        budget=None if rng.random() < 0.6 else int(rng.integers(0, 6)))
+            env, orc = HeatAlertEnv(weights="linear", tables=dt, device="cuda:0", **ctor), O.OracleEnv(rd, **ctor)
+            log = [f"variant {variant} sequence {seq} ctor {ctor}"]
+            fresh = True
+            for _ in range(int(rng.integers(40, 90))):
+                if fresh or rng.random() < 0.12:
+                    kw = dict(location=None if rng.random() < 0.5 else str(rng.choice(sd.fips_list)),
+                              similar_climate_counties=[None, True, False][int(rng.integers(0, 3))],
+                              seed=None if rng.random() < 0.2 else int(rng.integers(0, 10000)),
+                              budget=None if rng.random() < 0.5 else int(rng.integers(0, 8)),
+                              sample_budget=bool(rng.random() < 0.35),
+                              sample_budget_type=str(rng.choice(["less_than", "centered"])))
+                    log.append(f"reset({kw})")
+                    g = int(rng.integers(0, 1 << 30))  # seed=None draws from the GLOBAL generator: same state for both
+                    np.random.seed(g)
+                    o1, i1 = env.reset(**kw)
+                    np.random.seed(g)
+                    o2, i2 = orc.reset(**kw)
+                    r1 = r2 = None
+                    d1 = d2 = False
+                    fresh = False
+                else:
+                    a = int(rng.random() < 0.45)
+                    n_after_done += orc.t >= orc.n_days - 1 and len(orc.actual_alert_buffer) >= orc.n_days
+                    o1, r1, d1, tr, i1 = env.step(a)
+                    o2, r2, d2, _, i2 = orc.step(a)
+                    log.append(f"step({a}) -> done {d2}, t {orc.t}")
+                    assert tr is False
+                n_ops += 1
+                ctx = "\n".join(log[:1] + log[-12:])
+                assert np.array_equal(o1, o2.astype(np.float32)), ctx
+                if r1 is not None:
+                    assert abs(r1 - r2) <= 1e-5, (ctx, r1, r2)
+                    worst = max(worst, abs(r1 - r2))
+                assert d1 == d2, ctx
+                for k in ("episode_index", "remaining_budget", "at_budget", "location", "location_index", "feature_names"):
+                    assert i1[k] == i2[k], (ctx, k, i1[k], i2[k])
+                assert (env.t, env.alert_streak, env.budget, env.coef_index, env.n_days, env.remaining_budget, env.at_budget) == \
+                    (orc.t, orc.alert_streak, orc.budget, orc.coef_index, orc.n_days, orc.remaining_budget, orc.at_budget), ctx
+            env.close()
+    print(f"drop-in sequences: {n_ops} operations, {n_after_done} steps on finished episodes, max |reward - oracle| {worst:.2e}")
+    assert n_ops > 3000 and n_after_done > 100 and worst <= 1e-5
