@@ -127,3 +127,45 @@ def test_vector_env_is_a_gymnasium_vector_env_when_gymnasium_is_importable(monke
         importlib.reload(envmod)
     assert envmod.HeatAlertVecEnv.__mro__[1] is object
     assert envmod.HeatAlertVecEnv.metadata["autoreset_mode"] == "same_step" and envmod._autoreset_metadata("disabled") == "disabled"
+
+
+def test_kernel_options_record_and_overrides():
+    """The switches that select HOW things are computed live in one record; each is still accepted by name."""
+    from weather2alert_amd import KernelOptions
+
+    k = KernelOptions()
+    assert (k.step_kernel, k.write_obs, k.rollout_order, k.rollout_mfma, k.pm_kernel) == ("auto", True, True, True, "matrix_i8")
+    k2 = k.with_overrides(step_kernel="wide", pm_kernel="vector")
+    assert k2.step_kernel == "wide" and k2.pm_kernel == "vector" and k.step_kernel == "auto"  # frozen: a new record
+    with pytest.raises(ValueError, match="removed"):
+        KernelOptions(reward_path="table")
+    with pytest.raises(ValueError):
+        k.with_overrides(step_kernel="fastest")
+    with pytest.raises(TypeError):
+        k.with_overrides(step_kernal="wide")
+
+
+def test_library_is_rebuilt_on_content_not_on_file_times(tmp_path, monkeypatch):
+    """needs_build() compares a hash of the sources with the sidecar build_lib() wrote: touching a source (a fresh
+    checkout, a copy) does not ask for a rebuild, changing one does; a library without a sidecar falls back to file
+    times."""
+    import os
+    import time
+
+    from weather2alert_amd import build as b
+
+    if not os.path.exists(b.LIB) or not os.path.exists(b.HASH_FILE):
+        pytest.skip("library not built in this tree")
+    assert not b.needs_build()
+    src = b._dep_files()[0]
+    st = os.stat(src)
+    try:
+        os.utime(src, (time.time() + 3600, time.time() + 3600))  # looks newer than the library
+        assert not b.needs_build()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    monkeypatch.setattr(b, "build_hash", lambda: "0" * 64)  # as if a source had changed
+    assert b.needs_build()
+    monkeypatch.undo()
+    monkeypatch.setenv("W2A_CXXFLAGS", "-DLANES=8")  # other compiler flags = another library
+    assert b.needs_build()

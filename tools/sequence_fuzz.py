@@ -363,6 +363,37 @@ class Runner:
         e.rollout_mfma = m.rollout_mfma = bool(rng.random() < 0.8)
         self.log.append(f"switch: step_kernel={sk}, rollout_order={e.rollout_order}, rollout_mfma={e.rollout_mfma}")
 
+    def op_c_level_empty_reset(self):
+        """Straight at the C ABI, past the Python class: a masked device-RNG reset whose mask selects NO env. No env
+        changes, but the handle cannot know that: it must drop what it knew (lock-step day, packed form, tile list) and
+        -- posterior-mean mode -- refuse the reward kernel until the envs are grouped by column again (the flag whose
+        staleness the round-2 advisor found by reading; the Python class regroups after every reset of its own, so only
+        a direct call can see it)."""
+        e, m = self.env, self.m
+        with torch.cuda.device(self.dev):
+            if e._sort_ws is not None and self.rng.random() < 0.5:
+                # episode_order="sorted": the relabelling sort once more. The envs are already in key order and the sort
+                # is stable, so nobody moves -- but the handle must again treat every index as holding another episode
+                self.log.append("C level: w2a_sort_episodes (already sorted: the identity)")
+                _ffi.check(e._lib.w2a_sort_episodes(e._h, e._sort_ws.data_ptr(), e._sort_ws.numel(), e._stream()),
+                           "w2a_sort_episodes")
+                m.rm_valid, m.packed_current = False, False
+            else:
+                self.log.append("C level: w2a_reset_device_rng(mask = nobody)")
+                zero = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
+                _ffi.check(e._lib.w2a_reset_device_rng(e._h, *e._reset_cfg, 1, zero.data_ptr(), e._obs_ptr, e._stream()),
+                           "w2a_reset_device_rng")
+                m._note_cfg(m.reset_cfg)
+                m._note_launch_reset(masked=True)
+            torch.cuda.synchronize()
+            if m.pm:
+                act = torch.zeros(self.n, dtype=torch.int32, device=self.dev)
+                rc = e._lib.w2a_posterior_mean_reward(e._h, act.data_ptr(), _ffi.ACT_I32, e._rew_ptr, e._stream())
+                if rc == 0:
+                    self.fail("C level: w2a_posterior_mean_reward ran on a column grouping that a reset had outdated")
+        e._regroup()
+        m.py_order_stale = True
+
     def op_graph(self):
         """A block of K step() calls captured into a hipGraph and replayed R times (autoreset in the kernel or disabled:
         the host must have nothing to do between the steps of a replayed block)."""
@@ -416,6 +447,8 @@ class Runner:
             partial_ok = not sorted_mode and not pm_auto  # masks / tuples: refused there by the env (by design)
             ops = [("step", 40), ("burst", 6), ("rollout_part", 6), ("rollout_whole", 3), ("reset", 5), ("state", 6),
                    ("ckpt", 3), ("status", 3), ("invalidate", 2), ("switch", 2)]
+            if not m.pending_reset:
+                ops.append(("c_reset", 2))
             if partial_ok:
                 ops += [("reset_masked", 5), ("tuples", 3), ("tuples_masked", 3)]
             if self.ckpt is not None:
@@ -454,6 +487,8 @@ class Runner:
                 self.op_graph()
             elif op == "switch":
                 self.op_switch_kernel()
+            elif op == "c_reset":
+                self.op_c_level_empty_reset()
             elif op == "status":
                 self.log.append("check_status()")
                 self.check_status("check_status()", self.expect_status)

@@ -62,7 +62,9 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # W2A_LIB: load another build of the library instead of the in-tree one (tools/mutation_fuzz.py: deliberately broken
+    # builds that the call-sequence fuzz has to catch). Never set in normal use.
+    return os.environ.get("W2A_LIB") or _build.LIB
 
 
 def load(build_if_missing: bool = True):
@@ -71,7 +73,7 @@ def load(build_if_missing: bool = True):
     if _lib is not None:
         return _lib
     path = lib_path()
-    if build_if_missing and _build.needs_build():
+    if build_if_missing and not os.environ.get("W2A_LIB") and _build.needs_build():
         try:
             _build.build_lib()
         except Exception as e:  # noqa: BLE001
