@@ -323,7 +323,9 @@ enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT =
 int w2a_query(w2a_env *env, int what);
 
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived
- * form (lock-step mirror, column grouping, what is known about days and budgets). */
+ * form (lock-step mirror, column grouping, what is known about days and budgets). The one call besides
+ * w2a_read_status that SYNCHRONISES: it waits for the device (whatever stream wrote the buffer) and scans the restored
+ * state for its largest budget, current and sticky, so that nothing has to be stated afterwards. */
 int w2a_invalidate(w2a_env *env);
 /* The library tracks an upper bound of every budget the state buffer holds -- the current episodes' and the sticky
  * ones later device-RNG resets hand out again (env.py:167-170) -- from the reset arguments (the packed lock-step form
@@ -334,8 +336,8 @@ int w2a_invalidate(w2a_env *env);
  *                         (sticky budgets of earlier episodes live on). If that was "no bound exists" -- a sticky
  *                         W2A_BUDGET_CENTERED budget is a random walk, also inside the kernels -- the statement changes
  *                         nothing: the unbounded values are still there as sticky budgets.
- *   after w2a_invalidate: `bound` must cover EVERYTHING the restored buffer holds, sticky budgets included
- *                         (w2a_state_view.budget and .sticky_budget), and is taken as such.
+ *   after w2a_invalidate: nothing needs stating (the library has scanned the restored buffer, sticky budgets included); a
+ *                         `bound` given anyway only ever raises what it found.
  * The parameters of w2a_set_autoreset keep counting on top of either (in-kernel autoresets go on drawing with them). */
 int w2a_set_budget_bound(w2a_env *env, int64_t bound);
 

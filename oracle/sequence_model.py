@@ -501,13 +501,15 @@ class HandleModel:
     def note_invalidate(self):
         self.bound = self.bound_known = INF
         self.foreign = True
+        # w2a_invalidate scans the buffer itself: the largest budget it holds, current and sticky
+        self.note_set_budget_bound(int(max(int(self.V.budget.max()), int(self.sticky.max()), 0)))
         self.known_day = -1
         self.rm_valid = False
         self.packed_current = False
 
     def restore(self, d: dict):
-        """env.load_state_dict(...): the arrays come back; the handle forgets what it knew (w2a_invalidate), is told
-        the budgets' maximum, and gets the checkpoint's autoreset parameters again."""
+        """env.load_state_dict(...): the arrays come back; the handle forgets what it knew and scans the buffer for its
+        largest budget (w2a_invalidate), and gets the checkpoint's autoreset parameters again."""
         for k in self._CKPT:
             if k == "V":
                 for f, v in d["V"].items():
@@ -517,7 +519,6 @@ class HandleModel:
         if not (self.lockstep and self.autoreset == "next_step"):
             self.pending_reset = False
         self.note_invalidate()
-        self.note_set_budget_bound(int(max(int(self.V.budget.max()), int(self.sticky.max()), 0)))
         if self.reset_cfg is not None:
             self._note_cfg(self.reset_cfg, set_autoreset=True)
         self.py_order_stale = True

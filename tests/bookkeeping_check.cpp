@@ -53,7 +53,6 @@ struct World {
   Cfg acfg{-1, 0, 1};
   bool graph_recorded = false;
   bool graph_auto = false, graph_next = false;  // the recorded step carried W2A_STEP_AUTORESET (| W2A_STEP_NEXT_STEP)
-  bool foreign = false;  // a checkpoint was restored and the handle has not been told a bound covering its budgets yet
   // ---- the handle
   W2aBook bk;
   std::vector<std::string> trace;
@@ -149,13 +148,6 @@ static void api_reset_tuples(World &w, bool with_budgets, int64_t bmax, bool mas
   w.epoch = ++w.clock;
   write_canon(w);
   if (tell_bound) {  // HeatAlertVecEnv._reset_tuples: w2a_set_budget_bound(max of the budgets handed over)
-    if (w.foreign) {  // include/w2a.h: the first bound stated after w2a_invalidate must cover the WHOLE restored state,
-      for (int i = 0; i < NE; ++i) {  // sticky budgets included (the handle has never seen them)
-        if (w.budget[i] > seen) seen = w.budget[i];
-        if (w.sticky[i] > seen) seen = w.sticky[i];
-      }
-      w.foreign = false;
-    }
     bk_set_budget_bound(w.bk, seen);
     w.trace.push_back("    w2a_set_budget_bound(" + std::to_string(seen) + ")");
   }
@@ -272,11 +264,11 @@ static void api_invalidate(World &w, bool tell) {  // the caller restored a chec
   w.epoch = ++w.clock;
   write_canon(w);
   bk_invalidate(w.bk);
-  w.foreign = !tell;
-  if (tell) {  // HeatAlertVecEnv.load_state_dict: max over budgets AND sticky budgets of the restored state
+  {  // w2a_invalidate scans the restored buffer itself (k_budget_scan): largest budget, current and sticky
     int64_t m = 0;
     for (int i = 0; i < NE; ++i) { if (w.budget[i] > m) m = w.budget[i]; if (w.sticky[i] > m) m = w.sticky[i]; }
     bk_set_budget_bound(w.bk, m);
+    if (tell) bk_set_budget_bound(w.bk, w.rng->below(m + 1));  // a caller's (possibly smaller) statement changes nothing
   }
 }
 

@@ -70,6 +70,45 @@ def test_policy_loop_over_a_ragged_batch_raises_no_status_bit():
         env.close()
 
 
+def test_restored_sticky_budget_above_16_bits_never_reaches_the_packed_state():
+    """Finding 5 of the fuzz (round 4, sequence 77 of seed 99): episodes with a sticky budget of 65 721, a checkpoint
+    restore (w2a_invalidate) after which nothing was stated about budgets, a reset with injected tuples whose small
+    budgets the caller then stated -- the handle took that as covering the whole buffer, and the next sticky device
+    reset handed 65 721 to the 16-bit packed form: rewards off by 5. w2a_invalidate now scans the restored buffer
+    itself (current and sticky budgets)."""
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd import HeatAlertVecEnv, _ffi, synth, tables
+
+    sd = synth.make_synth("linear", n_fips=18, years=[2006, 2007, 2008], n_samples=6, n_days=5, seed=0, extra_confounder_fips=2)
+    ct = tables.compile_from_synth(sd)
+    n, dev = 64, torch.device("cuda:0")
+    env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel="wide")
+    env.reset(seed=1, options={"budget": 65721})  # sticky from here on (Q9)
+    env.step(torch.ones(n, dtype=torch.int32, device=dev))
+    env.state()
+    _ffi.check(env._lib.w2a_invalidate(env._h), "w2a_invalidate")  # as after a restore; nothing stated afterwards
+    assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 0  # the library found 65 721 in the buffer by itself
+    rng = np.random.default_rng(0)
+    county = rng.integers(0, ct.S, n)
+    env.reset(seed=2, options={"episodes": dict(county_w=np.asarray(ct.fips_to_weather)[county], year_i=rng.integers(0, ct.Y, n),
+                                                coef_col=county, sample=rng.integers(0, ct.n_samples, n),
+                                                budget=rng.integers(0, 9, n))})
+    assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 0  # the sticky 65 721 is still in the buffer
+    env.reset(seed=3)  # device RNG, sticky: every env gets 65 721 again
+    st = {k: v.cpu().numpy() for k, v in env.state().items()}
+    assert (st["budget"] == 65721).all()
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    for _ in range(3):
+        a = (rng.random(n) < 0.5).astype(np.int32)
+        _, r, _, _, _ = env.step(torch.as_tensor(a, device=dev))
+        _, r_o, _, _ = V.step(a)
+        assert np.abs(r.cpu().numpy() - r_o).max() <= 1e-5 and not env.packed_state
+    env.close()
+
+
 def test_dropin_env_random_call_sequences():
     """The num_envs = 1 drop-in (`HeatAlertEnv`, NumPy-seed parity) under random interleavings of reset(**kwargs) and
     step() against the scalar `OracleEnv` -- the line-by-line restatement of env.py:107-262 that is pinned bit-exact to

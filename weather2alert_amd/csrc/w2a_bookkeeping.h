@@ -91,10 +91,10 @@ static inline void bk_note_budgets(W2aBook &b, int64_t cand, bool centered, bool
   if (centered) cand = cand + cand / 2 + 1;
   if (cand > b.budget_bound) b.budget_bound = cand;
 }
-// The caller states that no budget handed over in device memory exceeds `bound`. After w2a_invalidate (a restored
-// checkpoint) the statement must cover EVERYTHING the restored buffer holds, sticky budgets included, and is taken as
-// such; otherwise it is combined with what the handle knew before the budgets went out of sight -- which may be
-// "nothing can be known" (W2A_BK_UNKNOWN: sticky random walk), and then stays so.
+// The caller states that no budget handed over in device memory exceeds `bound`. The first statement after
+// bk_invalidate comes from the library itself (w2a_invalidate scans the restored buffer for its largest budget, sticky
+// ones included) and is taken as covering everything; any other is combined with what the handle knew before the
+// budgets went out of sight -- which may be "nothing can be known" (W2A_BK_UNKNOWN: sticky random walk), and then stays so.
 static inline void bk_set_budget_bound(W2aBook &b, int64_t bound) {
   if (bound < 0) { b.budget_bound = W2A_BK_UNKNOWN; return; }
   if (b.foreign) {

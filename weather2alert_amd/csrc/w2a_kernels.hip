@@ -761,9 +761,31 @@ int w2a_query(w2a_env *env, int what) {
   }
 }
 
+// largest budget the state buffer holds: the current episodes' (stepc.a) and the sticky ones (cold.z, -1 = unset)
+__global__ void k_budget_scan(StateArrays st, int64_t n, int32_t *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t b = 0;
+  if (i < n) b = max((int32_t)st.stepc[i].a, (int32_t)st.cold[i].z);
+  for (int off = 32; off; off >>= 1) b = max(b, __shfl_xor(b, off));
+  if ((threadIdx.x & 63) == 0 && b > 0) atomicMax(out, b);
+}
+
 int w2a_invalidate(w2a_env *env) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
   bk_invalidate(env->bk);
+  // What was known about budgets described another buffer, and the restored one may hold budgets -- sticky ones too --
+  // that no later reset argument will ever mention. The handle reads them itself: a rare call (checkpoint restore), so it
+  // may wait for whatever the caller used to write the buffer (found by tools/sequence_fuzz.py, seed 99 sequence 77: a
+  // caller's bound stated after a later w2a_reset covered the new budgets only, a restored sticky budget of 65 721 then
+  // reached the 16-bit packed form)
+  HIP_TRY(hipDeviceSynchronize());
+  int32_t *d_max = reinterpret_cast<int32_t *>(const_cast<int32_t *>(env->slot_obs)) + ROWF + 1;  // header scratch word 33
+  int32_t h_max = 0;
+  HIP_TRY(hipMemcpy(d_max, &h_max, sizeof(h_max), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_budget_scan, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, 0, env->st, env->n, d_max);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost));
+  bk_set_budget_bound(env->bk, (int64_t)h_max);  // the first statement after bk_invalidate: taken as covering everything
   return W2A_OK;
 }
 

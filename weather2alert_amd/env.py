@@ -408,10 +408,10 @@ class HeatAlertVecEnv(_VectorEnvBase):
         hdr = self._state[:256].clone()  # slot map written by w2a_create for THIS handle
         self._state.copy_(sd["state"])
         self._state[:256].copy_(hdr)
-        _ffi.check(self._lib.w2a_invalidate(self._h), "w2a_invalidate")  # the state buffer changed behind the library
-        st = self.state()  # budgets of the restored episodes, incl. the sticky ones later resets may reuse
-        _ffi.check(self._lib.w2a_set_budget_bound(self._h, int(max(int(st["budget"].max()), int(st["sticky_budget"].max()), 0))),
-                   "w2a_set_budget_bound")
+        # the state buffer changed behind the library: it forgets what it derived and scans the restored buffer for its
+        # largest budget, sticky ones included (the one call that waits for the device)
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.w2a_invalidate(self._h), "w2a_invalidate")
         self._obs.copy_(sd["obs"])
         self._final_return.copy_(sd["final_return"])
         self._reward.copy_(sd["reward"])
