@@ -87,7 +87,7 @@ def draw_config(rng):
                reward_mode="posterior_mean" if pm else "sampled", episode_order=order,
                pm_kernel=str(rng.choice(["vector", "matrix", "matrix_i8"])),
                augment=bool(rng.random() < 0.5) or "augment" in fixes,
-               ctor_budget=None if rng.random() < 0.75 else int(rng.integers(0, 7)),
+               ctor_budget=None if rng.random() < 0.75 else int(rng.integers(0, 7)) if (pm or rng.random() < 0.85) else 66000,
                gid0=int(rng.integers(0, 1 << 20)), write_obs=bool(rng.random() < 0.92),
                rollout_order=bool(rng.random() < 0.8), rollout_mfma=bool(rng.random() < 0.8))
     return key, cfg
@@ -208,7 +208,7 @@ class Runner:
             opts["similar_climate_counties"] = bool(rng.random() < 0.5) or "augment" in self.cfg["fixes"]
         if rng.random() < 0.4:
             # now and then a budget the 16-bit packed form cannot hold: the handle must notice from the arguments
-            opts["budget"] = int(rng.integers(0, 8)) if (self.m.pm or rng.random() < 0.9) else int(rng.integers(65530, 70000))
+            opts["budget"] = int(rng.integers(0, 8)) if (self.m.pm or rng.random() < 0.85) else int(rng.integers(65530, 70000))
         if rng.random() < 0.3:
             opts["sample_budget"] = True
             opts["sample_budget_type"] = str(rng.choice(["less_than", "centered"]))
@@ -228,7 +228,7 @@ class Runner:
         cw = np.asarray(ct.fips_to_weather)[county].astype(np.int64)
         yi = rng.integers(0, ct.Y, n)
         ep = dict(county_w=cw, year_i=yi, coef_col=rng.integers(0, ct.S, n), sample=rng.integers(0, ct.n_samples, n),
-                  budget=None if rng.random() < 0.3 else rng.integers(0, 9 if (self.m.pm or rng.random() < 0.9) else 70000, n))
+                  budget=None if rng.random() < 0.3 else rng.integers(0, 9 if (self.m.pm or rng.random() < 0.85) else 70000, n))
         seed = int(rng.integers(0, 1 << 40))
         mask = (rng.random(n) < rng.choice([0.1, 0.5, 0.9])) if masked else None
         self.log.append(f"reset(seed={seed}, episodes=<tuples, budget {'table' if ep['budget'] is None else 'array'}>, "
