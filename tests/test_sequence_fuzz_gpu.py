@@ -176,3 +176,79 @@ def test_dropin_env_random_call_sequences():
             env.close()
     print(f"drop-in sequences: {n_ops} operations, {n_after_done} steps on finished episodes, max |reward - oracle| {worst:.2e}")
     assert n_ops > 3000 and n_after_done > 100 and worst <= 1e-5
+
+
+def test_vector_env_numpy_parity_sequences():
+    """seed_mode="numpy_parity" (the host replays NumPy's Generator per env, env.py:143-178) under random sequences
+    against one scalar OracleEnv per env: per-env reset kwargs, masked resets, the per-env sticky budget (Q9), and the
+    host-driven same_step autoreset, which re-seeds finished envs from the GLOBAL NumPy generator in env order
+    (env.py:143-144) -- replayed on the oracle side by re-seeding that generator identically."""
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+    from weather2alert_amd import HeatAlertVecEnv, synth, tables
+    from weather2alert_amd.tables import DeviceTables
+
+    dev = torch.device("cuda:0")
+    sd = synth.make_synth("linear", n_fips=12, years=[2006, 2007], n_samples=3, n_days=6, seed=61, extra_confounder_fips=2)
+    rd = O.RefData.from_synth(sd)
+    dt = DeviceTables(tables.compile_from_synth(sd), dev)
+    n_ops = n_auto = 0
+    for seq in range(30):
+        rng = np.random.default_rng([11, seq])
+        n = int(rng.integers(1, 7))
+        autoreset = str(rng.choice(["same_step", "disabled"]))
+        aug, cb = bool(rng.random() < 0.4), (None if rng.random() < 0.6 else int(rng.integers(0, 5)))
+        env = HeatAlertVecEnv(n, tables=dt, device=dev, seed_mode="numpy_parity", autoreset=autoreset,
+                              similar_climate_counties=aug, budget=cb)
+        orcs = [O.OracleEnv(rd, similar_climate_counties=aug, budget=cb) for _ in range(n)]
+        last = {}
+        first = True
+        for _ in range(int(rng.integers(30, 70))):
+            if first or rng.random() < 0.15:
+                mask = None if (first or rng.random() < 0.5) else (rng.random(n) < 0.6)
+                opts = dict(location=[None if rng.random() < 0.5 else str(rng.choice(sd.fips_list)) for _ in range(n)],
+                            budget=None if rng.random() < 0.5 else int(rng.integers(0, 7)),
+                            sample_budget=bool(rng.random() < 0.3),
+                            sample_budget_type=str(rng.choice(["less_than", "centered"])))
+                seeds = [int(x) for x in rng.integers(0, 10000, n)]
+                o = dict(opts)
+                if mask is not None:
+                    o["mask"] = mask
+                obs, info = env.reset(seed=seeds, options=o)
+                last = {k: v for k, v in opts.items() if k != "location"}
+                last["location"] = opts["location"]
+                for i in range(n):
+                    if mask is None or mask[i]:
+                        orcs[i].reset(location=opts["location"][i], seed=seeds[i], budget=opts["budget"],
+                                      sample_budget=opts["sample_budget"], sample_budget_type=opts["sample_budget_type"])
+                first = False
+                want_r = want_d = None
+            else:
+                a = (rng.random(n) < 0.5).astype(np.int32)
+                g = int(rng.integers(0, 1 << 30))
+                np.random.seed(g)
+                obs, r, d, _, info = env.step(torch.as_tensor(a, device=dev))
+                np.random.seed(g)
+                res = [orcs[i].step(int(a[i])) for i in range(n)]
+                want_r = np.asarray([x[1] for x in res])
+                want_d = np.asarray([x[2] for x in res])
+                if autoreset == "same_step":
+                    for i in range(n):  # DummyVecEnv-style: finished envs restart with a fresh global-RNG seed, in env order
+                        if want_d[i]:
+                            orcs[i].reset(location=last["location"][i], budget=last["budget"], sample_budget=last["sample_budget"],
+                                          sample_budget_type=last["sample_budget_type"])
+                            n_auto += 1
+                assert np.abs(r.cpu().numpy() - want_r).max() <= 1e-5 and np.array_equal(d.cpu().numpy(), want_d)
+            n_ops += 1
+            want_obs = np.stack([x.observation for x in orcs]).astype(np.float32)
+            assert np.array_equal(obs.cpu().numpy(), want_obs), (seq, n_ops)
+            st = {k: v.cpu().numpy() for k, v in env.state().items()}
+            assert list(st["t"]) == [x.t for x in orcs] and list(st["streak"]) == [x.alert_streak for x in orcs]
+            assert list(st["budget"]) == [x.budget for x in orcs] and list(st["sample"]) == [x.coef_index for x in orcs]
+            assert list(info["location"]) == [x.location for x in orcs]
+            assert list(info["episode_index"]) == [x.ep_index for x in orcs]
+            assert list(info["remaining_budget"].cpu().numpy()) == [x.budget - sum(x.actual_alert_buffer) for x in orcs]
+        env.close()
+    print(f"numpy_parity sequences: {n_ops} operations, {n_auto} host autoresets")
+    assert n_ops > 1000 and n_auto > 100
