@@ -1860,3 +1860,10 @@ def test_bench_json_contract_on_the_gpu(dev):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert 1e10 < d["value"] < 6e10  # 10-60 G env-steps/s: above the north-star target, below what 149 B per env-step allow
     assert d["status_bits"] == 0
+    # the line carries its own box's numbers, measured in the same process right after the timed region
+    assert 3000.0 < rf["copy_gbs_this_box"] < 8000.0, rf["copy_gbs_this_box"]
+    pu = rf["probe_us_this_box"]
+    assert pu["envs"] == n and 0 < pu["gathers_only"] < pu["streams_and_gathers"] and 0 < pu["streams_only"] < pu["streams_and_gathers"] * 1.05
+    assert abs(rf["kernel_over_probe"] - rf["avg_launch_us"] / pu["streams_and_gathers"]) < 1e-6 and 0.8 < rf["kernel_over_probe"] < 1.5
+    assert rf["traffic"] is None or "REPLAYED" in rf["traffic_provenance"]
+    assert d["single_gpu_value"] is None and d["collective_overhead_frac"] is None  # multi-GPU self-judging keys: N > 1 only
