@@ -59,13 +59,16 @@ def table_set(key):
     return _TABLE_CACHE[key]
 
 
+BIG = False  # --big: every sequence at >= 131 072 envs (the size from which step_kernel="auto" goes wide by itself)
+
+
 def draw_config(rng):
     n_days = int(rng.choice([3, 4, 5, 6, 8, 11, 16, 24, 40, 153], p=[.08, .1, .12, .14, .14, .14, .1, .08, .06, .04]))
     ragged = bool(rng.random() < 0.25)
     key = (int(rng.integers(3, 20)), int(rng.integers(1, 4)), int(rng.integers(1, 8)), n_days, ragged, int(rng.integers(0, 6)))
     u = rng.random()
     n = int(rng.choice(EDGE_N)) if u < 0.6 else int(rng.integers(1, 400)) if u < 0.95 else int(rng.integers(1025, 6000))
-    if u > 0.995 and n_days <= 16:
+    if (u > 0.995 or BIG) and n_days <= 16:
         n = 131072 + int(rng.integers(0, 300))  # step_kernel="auto" picks the 64-envs-per-wave kernel by itself from here
     pm = bool(rng.random() < 0.2)
     autoreset = str(rng.choice(["same_step", "next_step", "disabled"], p=[.45, .3, .25]))
@@ -534,7 +537,10 @@ def main():
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--keep-going", type=int, default=0, help="report up to this many failing sequences instead of stopping at the first")
+    ap.add_argument("--big", action="store_true", help="batches of >= 131 072 envs in every sequence with episodes <= 16 days")
     a = ap.parse_args()
+    global BIG
+    BIG = a.big
     dev = torch.device("cuda:0")
     t0 = time.time()
     tot: dict = {}
