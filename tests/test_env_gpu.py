@@ -85,6 +85,42 @@ def test_dropin_env_reproduces_reference_goldens(mini, dev):
         env.close()
 
 
+def test_dropin_env_replays_reference_call_sequences(mini, golden_dir, dev):
+    """The drop-in env against call SEQUENCES recorded from the unmodified reference (tests/golden/make_golden_r4.py:
+    9 361 operations on 14 env objects -- resets in the middle of episodes with every kwarg, seed=None through the global
+    NumPy generator, 449 steps after `done`): observations bit-exact (as float32), rewards within 1e-5 of the
+    REFERENCE's float64, done / info / attributes exact."""
+    from weather2alert_amd import HeatAlertEnv
+
+    _, _, ct, dt, _ = mini
+    d = dict(np.load(os.path.join(golden_dir, "mini_sequences.npz")))
+    meta = json.loads(str(d["meta_json"]))
+    k, worst = 0, 0.0
+    for si, q in enumerate(meta["sequences"]):
+        env = HeatAlertEnv(weights="linear", tables=dt, device=dev, **q["ctor"])
+        resets = {r["at"]: r for r in q["resets"]}
+        strs = {r["at"]: r for r in meta["info_str"][si]}
+        cur = None
+        for i in range(q["n_ops"]):
+            if i in resets:
+                np.random.seed(resets[i]["global_seed"])
+                obs, info = env.reset(**resets[i]["kwargs"])
+                cur = (strs[i]["episode_index"], strs[i]["location"])
+            else:
+                obs, r, done, trunc, info = env.step(int(d["action"][k]))
+                worst = max(worst, abs(r - d["reward"][k]))
+                assert abs(r - d["reward"][k]) <= REWARD_TOL and done == d["done"][k] and trunc is False, (si, i)
+            np.testing.assert_array_equal(obs, d["obs"][k].astype(np.float32), err_msg=f"sequence {si} op {i}")
+            assert (info["remaining_budget"], int(info["at_budget"]), info["location_index"]) == tuple(d["info_int"][k]), (si, i)
+            assert (info["episode_index"], info["location"]) == cur, (si, i)
+            got = [env.t, env.alert_streak, env.budget, env.coef_index, env.n_days, env.remaining_budget, int(env.at_budget)]
+            assert got == list(d["attrs"][k]), (si, i, got, list(d["attrs"][k]))
+            k += 1
+        env.close()
+    assert k == len(d["obs"])
+    print(f"reference call sequences: {k} operations, max |reward - reference| = {worst:.2e}")
+
+
 def test_vector_env_equals_goldens_batched(mini, dev):
     """All golden episodes as one batch with injected episode tuples (ragged N = 58)."""
     from weather2alert_amd import HeatAlertVecEnv
