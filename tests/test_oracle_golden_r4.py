@@ -55,3 +55,27 @@ def test_scalar_oracle_reproduces_reference_call_sequences(seqs):
         got = [env.t, env.alert_streak, env.budget, env.coef_index, env.n_days, env.remaining_budget, int(env.at_budget)]
         assert got == list(d["attrs"][k]), (si, i, dict(zip(A, got)), dict(zip(A, d["attrs"][k])))
     assert k + 1 == len(d["obs"]) == 9361 and n_after_done > 300 and n_mid_resets > 40
+
+
+def test_vector_oracle_reproduces_reference_call_sequences(seqs):
+    """The vectorised oracle (what the GPU parity tests and the call-sequence model compute with) on the same recording,
+    one env at a time: episode tuples from what the reference reported at each reset; rewards, observations and done --
+    also for steps after `done` -- bit-exact against the reference."""
+    d, meta, data = seqs
+    fw = sorted({k[0] for k in data.episodes})
+    V = O.VectorOracle(data, fw, data.valid_years)
+    n_after = 0
+    for si, i, rs, st, k in iter_ops(d, meta):
+        if rs is not None:
+            f, y = st["episode_index"].split("_")
+            t, streak, budget, coef_index, n_days, rem, atb = (int(x) for x in d["attrs"][k])
+            obs = V.reset([fw.index(f)], [data.valid_years.index(int(y))], [int(d["info_int"][k][2])], [coef_index], [budget])
+            assert V.n_days[0] == n_days
+        else:
+            n_after += bool(V.t[0] >= V.n_days[0] - 1 and V.used[0] + 0 >= 0 and d["attrs"][k - 1][0] == V.n_days[0] - 1 and d["done"][k - 1])
+            obs, r, done, actual = V.step(np.asarray([int(d["action"][k])]))
+            assert r[0] == d["reward"][k] and bool(done[0]) == bool(d["done"][k]), (si, i)
+            assert [int(V.t[0]), int(V.streak[0]), int(V.budget[0] - V.used[0]), int(V.at_budget[0])] == \
+                [int(d["attrs"][k][0]), int(d["attrs"][k][1]), int(d["attrs"][k][5]), int(d["attrs"][k][6])], (si, i)
+        np.testing.assert_array_equal(obs[0], d["obs"][k], err_msg=f"sequence {si} op {i}")
+    assert n_after > 300
