@@ -371,12 +371,14 @@ class HeatAlertVecEnv(_VectorEnvBase):
         """Decoded per-env integer state (device tensors)."""
         return self._state_packed()[1]
 
-    def _state_packed(self):
-        """(one int32 [n_fields, N] buffer, dict of per-field views into it): a single D2H copy fetches all."""
+    def _state_packed(self, fields=None):
+        """(one int32 [n_fields, N] buffer, dict of per-field views into it): a single D2H copy fetches all.
+        fields: decode only these (w2a_state_view: a NULL array is skipped)."""
         v = _ffi.StateView()
-        buf = torch.empty((len(_ffi.STATE_FIELDS), self.num_envs), dtype=torch.int32, device=self.device)
+        names = _ffi.STATE_FIELDS if fields is None else [k for k in _ffi.STATE_FIELDS if k in fields]
+        buf = torch.empty((len(names), self.num_envs), dtype=torch.int32, device=self.device)
         out = {}
-        for i, k in enumerate(_ffi.STATE_FIELDS):
+        for i, k in enumerate(names):
             out[k] = buf[i].view(torch.float32) if k == "episode_return" else buf[i]
             setattr(v, k, buf[i].data_ptr())
         with torch.cuda.device(self.device):
@@ -765,7 +767,8 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                                  None if amask is None else amask.data_ptr(), words, self._fr_ptr,
                                                  None if snap is None else snap.data_ptr(), self._stream()), "w2a_rollout")
         self._keep_pol = keep
-        st = self.state()
+        # only what this call returns is decoded (sixteen arrays of N int32 otherwise: 64 MB of writes at 1 M envs)
+        st = self.state() if mask is not None else self._state_packed(("finished",))[1]
         out["done"] = st["finished"].bool()  # the terminal step has run (t stops at n_days-1 before AND after it)
         out["final_return"] = self._final_return.clone()  # meaningful where out["done"]
         if mask is not None:
