@@ -10,7 +10,10 @@
  *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch) unless marked host.
  *     The library allocates nothing on the device and frees nothing but the handle.
  *   - All calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- *     default stream). No call synchronises except w2a_read_status.
+ *     default stream). Three calls wait for the device: w2a_create (once per handle: it uploads the slot map and
+ *     scans the tables on the NULL stream, then hipDeviceSynchronize), w2a_invalidate and w2a_read_status (both
+ *     wait for `stream` only, to read a value back). Nothing else synchronises or allocates, so everything
+ *     else may be recorded into a hipGraph (w2a_state_bytes below says what a recorded w2a_step implies).
  *   - Return value: 0 = W2A_OK, negative = error (w2a_last_error() gives the text). Nothing
  *     throws across the ABI. Arguments are validated on the host before any launch; values
  *     that live in device arrays (episode tuples, actions) are range-checked inside the
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 16
+#define W2A_ABI_VERSION 17
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -42,7 +45,10 @@ enum {
 enum {
   W2A_ST_BAD_EPISODE = 1, /* reset tuple out of range (reference: KeyError env.py:127 / ValueError :121) */
   W2A_ST_BAD_ACTION = 2,  /* action not in {0,1} (reference action_space = Discrete(2), env.py:95) */
-  W2A_ST_STEP_AFTER_DONE = 4  /* step() on a finished episode without autoreset */
+  W2A_ST_STEP_AFTER_DONE = 4, /* step() on a finished episode without autoreset */
+  W2A_ST_STALE_GRAPH = 8  /* a replayed hipGraph holds a w2a_step on the packed lock-step form of the state, and that form
+                             could not be kept current (the batch left lock step, budgets went out of sight, a checkpoint
+                             was restored): the replayed step did NOTHING -- see w2a_state_bytes */
 };
 
 /* action buffer element types accepted by w2a_step */
@@ -129,19 +135,31 @@ int w2a_abi_version(void);
 const char *w2a_last_error(void);
 
 /* Bytes of caller-owned device memory one handle needs for `num_envs` envs (256-B aligned): 40 B per env of
- * canonical state (episode record, read-only step constants, counters + return) and a 16-B lock-step mirror. While the
- * handle knows the batch to be in lock step -- every env reset together by an unmasked reset, one episode length for
- * every (county, year), plain steps since -- the day, the episode length and the `finished` bit are the same for
- * every env and travel as kernel arguments; the 64-envs-per-wave step kernel then streams 8 + 8 B of packed state per
- * env in and 8 B out instead of 12 + 12 and 12 (needs T <= 255, S < 65536, n_samples <= 1024, S_w * Y < 2^22 and
- * budgets <= 65535; anything else uses the canonical arrays). The library converts between the two forms by itself
- * whenever an entry point needs the other one; a caller that rewrites the state buffer behind the library's back
- * (checkpoint restore) must call w2a_invalidate. Stream capture: a w2a_step recorded into a hipGraph always uses the
- * canonical form (the packed kernel takes the day as an argument, which a replay would not advance), and the handle
- * keeps to it from then on: replays advance days -- and, with W2A_STEP_AUTORESET, re-draw episodes -- behind the
- * host's back, so such a handle never again claims to know the day (no packed steps, no matrix-core rollout), and after
- * a recorded autoreset step w2a_group_by_column no longer makes w2a_posterior_mean_reward available.
- * The decisions are plain C++ in csrc/w2a_bookkeeping.h (run on the CPU under sanitizers by tests/test_bookkeeping_cpu.py). */
+ * canonical state (episode record, read-only step constants, counters + return) and a 16-B lock-step mirror (+ one day
+ * word per 64 envs). While the handle knows the batch to be in lock step -- every env reset together by an unmasked
+ * reset, one episode length for every (county, year), plain steps and rollouts since -- the day and the episode length
+ * are the same for every env; the 64-envs-per-wave step kernel then streams 8 + 8 B of packed state per env in and 8 B
+ * out instead of 12 + 12 and 12, with the day in the mirror's per-tile day word (needs T <= 255, S < 65536, n_samples
+ * <= 1024, S_w * Y < 2^22 and budgets <= 65535; anything else uses the canonical arrays). The library converts between
+ * the two forms by itself whenever an entry point needs the other one; a caller that rewrites the state buffer behind
+ * the library's back (checkpoint restore) must call w2a_invalidate.
+ * Stream capture. Every step kernel reads the day from device memory, so a w2a_step recorded into a hipGraph steps
+ * correctly on every replay. What a recording fixes is the FORM of the state its kernel steps (no conversion between the
+ * forms is ever recorded: w2a_step fails with W2A_ERR_STATE if the form its kernel needs is not current -- step once
+ * eagerly, or call w2a_get_state, before capturing). From then on the handle keeps that form current at the end of
+ * every call, so that a replay may come at any time:
+ *   - recorded on the packed form (a lock-step batch of >= 131 072 envs, or W2A_STEP_WIDE, after one eager step): the
+ *     mirror stays the primary form; calls that work on the canonical words (resets, rollouts, state reads) convert
+ *     back before they return. Where the batch can no longer be packed (a masked reset, budgets handed over in device
+ *     memory without w2a_set_budget_bound, w2a_invalidate) the mirror is marked stale on the device and a replay of the
+ *     recorded step does nothing but raise W2A_ST_STALE_GRAPH -- until the next whole-batch reset makes it packable again.
+ *   - recorded on the canonical form: the handle never uses the packed form again.
+ *   Replays advance days behind the host's back: a handle with a recorded step answers W2A_Q_LOCKSTEP_DAY with -1 (it
+ *   still knows WHETHER the batch is in lock step, which is all the packed step and the matrix-core rollout need); after
+ *   a recorded W2A_STEP_AUTORESET step, which re-draws episodes on replay, it no longer claims lock step, a valid column
+ *   grouping (w2a_posterior_mean_reward) or a valid tile list (w2a_rollout_mfma_prepare) at all.
+ * The decisions are plain C++ in csrc/w2a_bookkeeping.h (run on the CPU under sanitizers, randomly and exhaustively, by
+ * tests/test_bookkeeping_cpu.py). */
 size_t w2a_state_bytes(int64_t num_envs);
 
 /* Replaces HeatAlertEnv.__init__ (env.py:20-105) for `num_envs` envs whose global ids are
@@ -274,8 +292,14 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
  * order -- per-env outputs, RNG streams and state stay indexed by env id. Call after a reset (the order of an
  * earlier episode stays valid as a permutation, it is just no longer sorted). workspace: caller-owned,
  * w2a_rollout_order_workspace_bytes(num_envs, S_w * Y) bytes, 256-B aligned, must stay alive while w2a_rollout is
- * used. */
+ * used -- and, once attached, until w2a_destroy.
+ *   w2a_rollout_order_attach  (host only) hands the workspace over ahead of time: from then on every whole-batch reset
+ *                             also counts the envs of each feature row and ranks every env inside its row there (the
+ *                             first pass of the counting sort, hidden behind the reset's observation stores), and
+ *                             w2a_rollout_order is left with a scan and an atomic-free placement. w2a_rollout_order
+ *                             attaches its workspace itself on first use. */
 size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows);
+int w2a_rollout_order_attach(w2a_env *env, void *workspace, size_t workspace_bytes);
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Optional, speed only: let w2a_rollout compute the table-sourced part of both logits -- 27 of their 30 terms, which do
@@ -313,20 +337,24 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
 
 /* What the handle knows (host-side bookkeeping, no device work): the day every env is on if the batch is known to be in
- * lock step (-1 otherwise); whether tables and budgets allow the lock-step mirror at all; which of the two forms of
- * the step state is current. */
-enum { W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3,
+ * lock step AND the host can know the day (-1 otherwise: not in lock step, past the terminal step, or a step of this
+ * handle was recorded into a hipGraph); whether tables and budgets allow the lock-step mirror at all; which of the two
+ * forms of the step state is current; whether the batch is known to be in lock step. */
+enum { W2A_Q_LOCKSTEP = 6,           /* 1: every env is known to be on the same day of an episode of the one length there is */
+       W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3,
        W2A_Q_LAST_ROLLOUT_KERNEL = 4 /* what the last w2a_rollout launched: -1 none yet, 0 k_rollout (4 lanes per env),
                                         1 k_rollout64 (lane = env), 2 k_rollout_mfma (int8 matrix cores) */,
        W2A_Q_LAST_STEP_KERNEL = 5    /* what the last w2a_step launched: -1 none yet, 0 k_step (4 lanes per env),
                                         1 k_step64 on the canonical state words, 2 k_step64 on the lock-step mirror */ };
 int w2a_query(w2a_env *env, int what);
 
-/* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part): forget every derived
- * form (lock-step mirror, column grouping, what is known about days and budgets). The one call besides
- * w2a_read_status that SYNCHRONISES: it waits for the device (whatever stream wrote the buffer) and scans the restored
- * state for its largest budget, current and sticky, so that nothing has to be stated afterwards. */
-int w2a_invalidate(w2a_env *env);
+/* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part) on `stream`: forget
+ * every derived form (lock-step mirror, column grouping, what is known about days and budgets). Waits for `stream` --
+ * and for nothing else on the device -- while it scans the restored state for its largest budget, current and sticky,
+ * so that nothing has to be stated afterwards (restored budgets below zero count as 0, as in the reset kernels).
+ * Fails with W2A_ERR_STATE while `stream` is recording a hipGraph. If the scan itself fails (W2A_ERR_HIP) the handle is
+ * still invalidated; budgets then stay unknown -- the packed form off -- until w2a_set_budget_bound. */
+int w2a_invalidate(w2a_env *env, void *stream);
 /* The library tracks an upper bound of every budget the state buffer holds -- the current episodes' and the sticky
  * ones later device-RNG resets hand out again (env.py:167-170) -- from the reset arguments (the packed lock-step form
  * holds budgets in 16 bits). Budgets handed over in DEVICE memory (w2a_reset with a budget array, a restored

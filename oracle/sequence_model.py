@@ -113,11 +113,12 @@ class HandleModel:
         self.pending_reset = False
         self.reset_cfg = None
         self.was_reset = False
-        # ---- mirror of the handle's bookkeeping (csrc/w2a_kernels.hip: w2a_env flags)
-        self.known_day = -1
+        # ---- mirror of the handle's bookkeeping (csrc/w2a_bookkeeping.h)
+        self.known_day = -1        # W2A_Q_LOCKSTEP_DAY
+        self.lock = False          # W2A_Q_LOCKSTEP
         self.bound, self.bound_known, self.foreign, self.auto_note = 0, 0, False, None
-        self.graph_captured = False
-        self.packed_current = False
+        self.graph_canon = self.graph_packed = self.graph_autoreset = False
+        self.pk_valid, self.canon_valid, self.poisoned = False, True, False
         self.order_set = False
         self.rm_valid = False
         self.py_order_stale = True
@@ -125,6 +126,37 @@ class HandleModel:
         self.last_rollout_kernel = -1
 
     # ------------------------------------------------------------------------------------------ helpers
+    @property
+    def packed_current(self) -> bool:
+        """HeatAlertVecEnv.packed_state: the mirror is current and the canonical words are not."""
+        return self.pk_valid and not self.canon_valid
+
+    @property
+    def any_graph(self) -> bool:
+        return self.graph_canon or self.graph_packed
+
+    def _can_pack(self) -> bool:
+        return self.bound <= 65535 and self.uni_nd > 0 and self.lock and not self.graph_canon
+
+    def _ensure_canonical(self):
+        self.canon_valid = True
+
+    def _canonical_modified(self, keeps_lock=True):
+        self.pk_valid = False
+        if not keeps_lock:
+            self.lock, self.known_day = False, -1
+
+    def _end_call(self):
+        """bk_end_call: after a recorded packed step the mirror stays the primary form."""
+        if not self.graph_packed:
+            return
+        if self.pk_valid:
+            self.canon_valid = False
+        elif self._can_pack():
+            self.pk_valid, self.canon_valid, self.poisoned = True, False, False
+        else:
+            self.poisoned = True
+
     def _mode(self) -> str:
         auto = self.autoreset in ("same_step", "next_step")
         if not auto:
@@ -168,11 +200,17 @@ class HandleModel:
             return
         if mode == BUDGET_CENTERED:
             cand = cand + cand // 2 + 1
+        if self.bound == INF:  # out of sight right now: what this reset can draw joins what a later statement restores
+            if self.bound_known != INF and cand > self.bound_known:
+                self.bound_known = cand
+            return
         if cand > self.bound:
             self.bound = cand
 
     def note_set_budget_bound(self, b):
         if b < 0:
+            if self.bound != INF:
+                self.bound_known = self.bound
             self.bound = INF
             return
         if self.foreign:  # the first statement after w2a_invalidate covers the whole restored buffer
@@ -187,10 +225,17 @@ class HandleModel:
             self._note_budgets(*self.auto_note)
 
     def _note_launch_reset(self, masked):
-        """launch_reset for from_tuples != 2."""
+        """launch_reset for from_tuples != 2 (bk_reset + bk_end_call)."""
         self.rm_valid = False
-        self.packed_current = False
-        self.known_day = 0 if (not masked and self.uni_nd > 0 and not self.graph_captured) else -1
+        if masked:
+            self._ensure_canonical()
+        self.canon_valid = True
+        self._canonical_modified(keeps_lock=False)
+        if not masked and self.uni_nd > 0:
+            self.lock = True
+            if not self.any_graph:
+                self.known_day = 0
+        self._end_call()
 
     def _note_cfg(self, cfg, set_autoreset=False):
         args = (cfg[3] if cfg[3] >= 0 else self.b0_max, cfg[4], cfg[5])
@@ -229,7 +274,12 @@ class HandleModel:
         if self.write_obs:
             self.obs = V.obs.astype(np.float32)  # w2a_observe re-emits every first observation
         self.rm_valid = False  # w2a_sort_episodes; ensure_canonical + canonical_modified(keeps lock step)
-        self.packed_current = False
+        self._ensure_canonical()
+        self._canonical_modified()
+        self._end_call()
+        if self.write_obs:  # w2a_observe
+            self._ensure_canonical()
+            self._end_call()
 
     # ------------------------------------------------------------------------------------------ reset
     def device_cfg(self, seed, options):
@@ -282,31 +332,56 @@ class HandleModel:
         self.was_reset = True
 
     # ------------------------------------------------------------------------------------------ step
-    def expect_step_kernel(self, flags_autoreset: bool) -> int:
-        wide = self.pm or self.step_kernel == "wide" or (self.step_kernel in ("auto", "unpacked") and self.n >= S64_MIN_ENVS)
-        if wide and self.step_kernel != "classic":
-            packed = (not self.pm and not flags_autoreset and self.step_kernel != "unpacked" and self.known_day >= 0 and
-                      self.bound <= 65535 and not self.graph_captured)
-            return 2 if packed else 1
-        return 0
+    def _wide(self) -> bool:
+        return (self.pm or self.step_kernel == "wide" or (self.step_kernel in ("auto", "unpacked") and self.n >= S64_MIN_ENVS)) \
+            and self.step_kernel != "classic"
 
-    def _note_step(self, flags_autoreset: bool, capturing: bool = False):
+    def expect_step_kernel(self, flags_autoreset: bool, capturing: bool = False) -> int:
+        """bk_step's plan: 0 k_step, 1 k_step64 on the canonical words, 2 k_step64 on the mirror; -1 refused (a capture
+        that would have to record a conversion of the state's form)."""
+        packed = (self._wide() and not self.pm and not flags_autoreset and self.step_kernel != "unpacked" and self._can_pack())
         if capturing:
-            self.graph_captured = True
-        k = self.expect_step_kernel(flags_autoreset)
+            if packed and not self.pk_valid:
+                packed = False
+            if not packed and not self.canon_valid:
+                return -1
+        return 2 if packed else (1 if self._wide() else 0)
+
+    def _note_step(self, flags_autoreset: bool, capturing: bool = False) -> int:
+        k = self.expect_step_kernel(flags_autoreset, capturing)
+        if k < 0:
+            return k
+        if flags_autoreset:
+            self.rm_valid = False
+        if capturing:
+            if k == 2:
+                self.graph_packed = True
+            else:
+                self.graph_canon = True
+                if flags_autoreset:
+                    self.graph_autoreset = True
         nxt = self.known_day + 1 if (not flags_autoreset and self.known_day >= 0 and self.known_day + 1 < self.uni_nd) else -1
-        if self.graph_captured:
+        if self.any_graph:
             nxt = -1
+        if k == 2:
+            self.pk_valid, self.poisoned = True, False
+            self.canon_valid = False
+        else:
+            self._ensure_canonical()
+            self._canonical_modified()
         self.known_day = nxt
         self.last_step_kernel = k
-        self.packed_current = k == 2
+        if k == 2 or not capturing:
+            self._end_call()
+        return k
 
-    def step(self, actions, dev_reward=None) -> dict:
+    def step(self, actions, dev_reward=None, note=True) -> dict:
         """env.step(actions). dev_reward: the f32 rewards the device returned for this call (each compared with the
         expected one by the caller): the handle adds those into its f32 episode return, so with them the model tracks
         the return to the last ulp or two (the compiler contracts `ret + c * base * (1 - eff)` into an FMA, so the
         kernel's sum is not always the sum of the ROUNDED reward it stored: 2 ulp of slack per step); without them
-        (graph replays) the per-step reward tolerance accumulates instead."""
+        (graph replays) the per-step reward tolerance accumulates instead. note=False: a REPLAYED step -- the device
+        advances, the handle's bookkeeping does not run."""
         n, V = self.n, self.V
         a = np.asarray(actions).astype(np.int64).copy()
         if self.pending_reset:  # host-driven next_step: this call restarts the whole batch, nothing is stepped
@@ -342,7 +417,8 @@ class HandleModel:
             # days without writing rows
             written = stepped & (~done | ("obs" in self.fixes))
             self.obs[written] = V.obs[written].astype(np.float32)
-        self._note_step(mode in ("dev_same", "dev_next"))
+        if note:
+            self._note_step(mode in ("dev_same", "dev_next"))
         rs = done if mode == "dev_same" else (restart_in if mode == "dev_next" else np.zeros(n, bool))
         if rs.any():
             idx = np.nonzero(rs)[0]
@@ -434,20 +510,22 @@ class HandleModel:
                 self.order_set, self.rm_valid, self.py_order_stale = True, False, False
                 if self.rollout_mfma and not self.fixbits:
                     self.rm_valid = True
+            if self.graph_autoreset:
+                self.rm_valid = False
             self.last_rollout_kernel = 2 if (self.rm_valid and self.order_set and not self.fixbits and
-                                             self.known_day >= 0) else (1 if self.order_set else 0)
-            self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd and
-                                                        not self.graph_captured) else -1
-            self.packed_current = False
+                                             self.lock) else (1 if self.order_set else 0)
+            self._note_rollout_begin(steps)
+            self._end_call()
         else:
             one_launch = self.pm_kernel != "matrix" and steps > 0
             if one_launch:
-                self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd and
-                                                            not self.graph_captured) else -1
+                self._note_rollout_begin(steps)
+                self._end_call()
             else:
-                for _ in range(steps):
+                for _ in range(steps):  # w2a_policy_actions, w2a_posterior_mean_reward (reads), w2a_step(REWARD_GIVEN)
+                    self._ensure_canonical()
+                    self._end_call()
                     self._note_step(False)
-            self.packed_current = False
         mode = self._mode()
         if mode in ("host_auto", "host_next") and self.finished.all():
             if mode == "host_auto":
@@ -456,13 +534,21 @@ class HandleModel:
                 self.pending_reset = True
         return out
 
+    def _note_rollout_begin(self, steps):
+        """bk_rollout_begin."""
+        self._ensure_canonical()
+        self._canonical_modified()
+        self.known_day = self.known_day + steps if (self.known_day >= 0 and self.known_day + steps < self.uni_nd and
+                                                    not self.any_graph) else -1
+
     # ------------------------------------------------------------------------------------------ read-backs
     def state(self) -> dict:
         V = self.V
         hist14 = np.zeros(self.n, np.int64)
         for k in range(14):
             hist14 |= V.hist[:, 13 - k].astype(np.int64) << k
-        self.packed_current = False  # w2a_get_state: ensure_canonical
+        self._ensure_canonical()  # w2a_get_state
+        self._end_call()
         return {"t": V.t, "used": V.used, "streak": V.streak, "hist14": hist14, "last_actual": V.last_actual,
                 "at_budget": V.at_budget.astype(np.int64), "budget": V.budget, "n_days": V.n_days,
                 "county_w": V.county_w, "year_i": V.year_i, "coef_col": V.coef_col, "sample": V.sample,
@@ -485,12 +571,18 @@ class HandleModel:
             return -1
         return int(V.t[0])
 
+    def uniform_truth(self) -> bool:
+        """Every env on the same day of an episode of the same length, all finished or none: what W2A_Q_LOCKSTEP = 1 claims."""
+        V = self.V
+        return len(np.unique(V.t)) == 1 and len(np.unique(V.n_days)) == 1 and len(np.unique(self.finished)) == 1
+
     # ------------------------------------------------------------------------------------------ checkpoints etc.
     _CKPT = ("V", "sticky", "episode_no", "finished", "ret32", "ret_tol", "final_return", "final_tol", "obs",
              "pending_reset", "reset_cfg", "lockstep", "was_reset")
 
     def snapshot(self) -> dict:
-        self.packed_current = False  # state_dict() starts with state()
+        self._ensure_canonical()  # state_dict() starts with state()
+        self._end_call()
         d = {}
         for k in self._CKPT:
             v = getattr(self, k)
@@ -503,9 +595,10 @@ class HandleModel:
         self.foreign = True
         # w2a_invalidate scans the buffer itself: the largest budget it holds, current and sticky
         self.note_set_budget_bound(int(max(int(self.V.budget.max()), int(self.sticky.max()), 0)))
-        self.known_day = -1
+        self.known_day, self.lock = -1, False
         self.rm_valid = False
-        self.packed_current = False
+        self.pk_valid, self.canon_valid = False, True
+        self._end_call()
 
     def restore(self, d: dict):
         """env.load_state_dict(...): the arrays come back; the handle forgets what it knew and scans the buffer for its

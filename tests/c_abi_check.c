@@ -27,6 +27,8 @@ int main(void) {
   if (w2a_sort_workspace_bytes(0) != 0) return 9;
   if (w2a_rollout_order_workspace_bytes(0, 10) != 0 || w2a_rollout_order_workspace_bytes(1000, 10) < 4 * 1000) return 11;
   if (w2a_rollout_order(NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 12;
+  if (w2a_rollout_order_attach(NULL, NULL, 0) != W2A_ERR_ARG) return 14;
+  if (w2a_invalidate(NULL, NULL) != W2A_ERR_ARG) return 15;
   printf("w2a C ABI v%d ok, sizeof(w2a_tables)=%zu\n", w2a_abi_version(), sizeof(w2a_tables));
   return 0;
 }

@@ -4,8 +4,9 @@ current, which day the envs are really on and which budgets they really hold (te
 sequences of every entry point that touches a validity flag (the round-2 advisor found two stale-flag
 bugs of this kind by reading, the GPU sequence fuzz covers the same ground end to end).
 
-Second half: MUTANTS of the header -- one rule broken each (a flag not cleared, a day not checked, a bound not kept) --
-must every one be caught by the same program. That is what says the harness would have seen such a bug."""
+Second half: the same program walks the ABSTRACT state space of the header breadth first to closure (nothing sampled).
+Third: MUTANTS of the header -- one rule broken each (a flag not cleared, a day not checked, a bound not kept) -- must
+every one be caught by the same program. That is what says the harness would have seen such a bug."""
 import os
 import shutil
 import subprocess
@@ -25,26 +26,26 @@ MUTANTS = [
     ("sort keeps a stale column grouping",
      "  b.perm_valid = 0;  // every env index now holds another episode: the column grouping is stale\n", "\n"),
     ("in-kernel autoreset keeps the column grouping",
-     "    b.perm_valid = 0;  // tile list go stale", "    //"),
+     "    b.perm_valid = 0;  // list and the row counts go stale\n", "\n"),
     ("modified canonical words leave the mirror marked current",
-     "  b.pk_valid = 0;\n  if (!keeps_lockstep) b.uni_t = -1;", "  if (!keeps_lockstep) b.uni_t = -1;"),
+     "  b.pk_valid = 0;\n  if (!keeps_lockstep) { b.lock = 0; b.uni_t = -1; }", "  if (!keeps_lockstep) { b.lock = 0; b.uni_t = -1; }"),
     ("reads of the canonical words never unpack", "  if (b.canon_valid) return;\n  d.unpack_state", "  return;\n  d.unpack_state"),
-    ("packed step leaves the canonical words marked current", "      b.canon_valid = 0;\n", "\n"),
+    ("packed step leaves the canonical words marked current", "    b.canon_valid = 0;\n    b.uni_t = uni_next;\n", "    b.uni_t = uni_next;\n"),
     ("lock-step day survives the terminal step", "b.uni_t + 1 < b.uni_nd) ? b.uni_t + 1 : -1;", "true) ? b.uni_t + 1 : -1;"),
-    ("masked reset claims lock step", "if (!masked && b.uni_nd > 0 && !b.graph_captured) b.uni_t = 0;",
-     "if (b.uni_nd > 0 && !b.graph_captured) b.uni_t = 0;"),
-    ("ragged tables claim lock step", "if (!masked && b.uni_nd > 0 && !b.graph_captured) b.uni_t = 0;",
-     "if (!masked && !b.graph_captured) b.uni_t = 0;"),
-    ("invalidate keeps the lock-step day", "b.pk_valid = 0; b.canon_valid = 1; b.uni_t = -1; b.perm_valid = 0;",
-     "b.pk_valid = 0; b.canon_valid = 1; b.perm_valid = 0;"),
-    ("invalidate keeps the mirror", "b.pk_valid = 0; b.canon_valid = 1; b.uni_t = -1; b.perm_valid = 0;",
-     "b.canon_valid = 1; b.uni_t = -1; b.perm_valid = 0;"),
-    ("a captured handle goes back to the packed form", "b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && !b.graph_captured;",
-     "b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET;"),
-    ("a captured handle keeps claiming the day after a reset", "if (!masked && b.uni_nd > 0 && !b.graph_captured) b.uni_t = 0;",
+    ("masked reset claims lock step", "if (!masked && b.uni_nd > 0) b.lock = 1;", "if (b.uni_nd > 0) b.lock = 1;"),
+    ("ragged tables claim lock step", "if (!masked && b.uni_nd > 0) b.lock = 1;", "if (!masked) b.lock = 1;"),
+    ("masked reset claims the day", "if (!masked && b.uni_nd > 0 && !bk_any_graph(b)) b.uni_t = 0;",
+     "if (b.uni_nd > 0 && !bk_any_graph(b)) b.uni_t = 0;"),
+    ("invalidate keeps lock step", "b.pk_valid = 0; b.canon_valid = 1; b.lock = 0; b.uni_t = -1; b.perm_valid = 0;",
+     "b.pk_valid = 0; b.canon_valid = 1; b.uni_t = -1; b.perm_valid = 0;"),
+    ("invalidate keeps the mirror", "b.pk_valid = 0; b.canon_valid = 1; b.lock = 0; b.uni_t = -1; b.perm_valid = 0;",
+     "b.canon_valid = 1; b.lock = 0; b.uni_t = -1; b.perm_valid = 0;"),
+    ("a handle with a recorded canonical step goes back to the packed form",
+     "return bk_packed_eligible(b) && b.lock && !b.graph_canon; }", "return bk_packed_eligible(b) && b.lock; }"),
+    ("a handle with a recorded step keeps claiming the day after a reset", "if (!masked && b.uni_nd > 0 && !bk_any_graph(b)) b.uni_t = 0;",
      "if (!masked && b.uni_nd > 0) b.uni_t = 0;"),
-    ("rollout to the end keeps the lock-step day", "(day >= 0 && day + n_steps < b.uni_nd && !b.graph_captured)",
-     "(day >= 0 && !b.graph_captured)"),
+    ("rollout to the end keeps the lock-step day", "(day >= 0 && day + n_steps < b.uni_nd && !bk_any_graph(b))",
+     "(day >= 0 && !bk_any_graph(b))"),
     ("a sticky centred budget counts as bounded", "  if (centered && sticky) { b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN; return; }\n", "\n"),
     ("a sticky random walk is forgotten by the next statement (the r3 rule)",
      "  if (centered && sticky) { b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN; return; }",
@@ -53,17 +54,42 @@ MUTANTS = [
     ("budgets in device memory count as known", "  if (cand < 0) { b.budget_bound = W2A_BK_UNKNOWN; return; }\n", "  if (cand < 0) return;\n"),
     ("a statement after a restore forgets the autoreset parameters",
      "  if (b.has_auto) bk_note_budgets(b, b.auto_cand, b.auto_centered != 0, b.auto_sticky != 0);\n", "\n"),
-    ("the packed form ignores the budget bound", "b.uni_t >= 0 &&\n                        b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET &&", "b.uni_t >= 0 &&"),
-    ("the packed form ignores the table limits", "!unpacked_flag && b.pk_static_ok && b.uni_t >= 0", "!unpacked_flag && b.uni_t >= 0"),
+    ("a reset with known arguments while budgets are out of sight is forgotten (round 5 finding)",
+     "    if (b.budget_bound_known != W2A_BK_UNKNOWN && cand > b.budget_bound_known) b.budget_bound_known = cand;\n", "\n"),
+    ("'unknown again' forgets what was known (round 5 finding)",
+     "    if (b.budget_bound != W2A_BK_UNKNOWN) b.budget_bound_known = b.budget_bound;\n    b.budget_bound = W2A_BK_UNKNOWN;\n    return;",
+     "    b.budget_bound = W2A_BK_UNKNOWN;\n    return;"),
+    ("the packed form ignores the budget bound", "return b.pk_static_ok && b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;",
+     "return b.pk_static_ok && b.uni_nd > 0;"),
+    ("the packed form ignores the table limits", "return b.pk_static_ok && b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;",
+     "return b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;"),
     ("a new visiting order keeps the old tile list", "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; b.rm_valid = 0; }",
      "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; }"),
     ("reset keeps the matrix-core rollout's tile list", "  b.rm_valid = 0;  // new episodes: the feature-row tile list of the matrix-core rollout is stale\n", "\n"),
-    ("the day restored on unpacking is the day after the terminal step", "b.pk_t = uni_next >= 0 ? uni_next : b.uni_t;", "b.pk_t = b.uni_t + 1;"),
-    ("a REWARD_GIVEN step runs packed", "const bool packed = !given && !autoreset", "const bool packed = !autoreset"),
-    ("an autoreset step runs packed", "const bool packed = !given && !autoreset &&", "const bool packed = !given &&"),
+    ("a REWARD_GIVEN step runs packed", "bool packed = wide_wanted && !given && !autoreset", "bool packed = wide_wanted && !autoreset"),
+    ("an autoreset step runs packed", "!given && !autoreset && !unpacked_flag && bk_can_pack(b);", "!given && !unpacked_flag && bk_can_pack(b);"),
     ("a rollout does not bring the canonical words up to date", "  const int32_t day = b.uni_t;\n  bk_ensure_canonical(b, d);", "  const int32_t day = b.uni_t;"),
     ("a rollout leaves the mirror marked current", "  bk_ensure_canonical(b, d);\n  bk_canonical_modified(b, true);\n  b.uni_t = (day >= 0",
      "  bk_ensure_canonical(b, d);\n  b.uni_t = (day >= 0"),
+    ("the matrix-core rollout runs without lock step", "if (b.rm_valid && b.has_order && !fixes && lock && mfma_built)",
+     "if (b.rm_valid && b.has_order && !fixes && mfma_built)"),
+    # ---- round 5: recorded graphs on either form, the poisoned mirror, row counts from k_reset
+    ("a capture records the conversion into the packed form", "    if (packed && !b.pk_valid) packed = false;\n", "\n"),
+    ("a capture records the conversion back to the canonical words", "    if (!packed && !b.canon_valid) { p.kernel = -1; return p; }\n", "\n"),
+    ("after a recorded packed step, a read leaves the canonical words marked current",
+     "  if (b.pk_valid) { b.canon_valid = 0; return; }  // a replay may step the mirror at any time from here on", "  if (b.pk_valid) return;"),
+    ("after a recorded packed step, nothing keeps the mirror current", "  if (!b.graph_packed) return;\n", "  return;\n"),
+    ("a mirror that cannot be kept current is not poisoned", "  } else if (!b.poisoned) {\n    d.poison_mirror();\n    b.poisoned = 1;\n  }", "  }"),
+    ("the mirror is re-packed although the batch cannot be packed", "  if (bk_can_pack(b)) {  // the canonical words were modified", "  if (true) {  //"),
+    ("a recorded autoreset step is not remembered", "      if (autoreset) b.graph_autoreset = 1;\n", "\n"),
+    ("an in-kernel autoreset keeps the row counts", "    b.hist_valid = 0;\n  }\n  if (capturing) {", "  }\n  if (capturing) {"),
+    ("a relabelling keeps the per-env ranks", "  b.hist_valid = 0;  // ... and so are the per-env ranks inside the feature rows\n", "\n"),
+    ("a masked reset leaves the row counts valid", "b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;",
+     "b.hist_valid = (b.has_order_ws && !b.graph_autoreset) ? 1 : 0;"),
+    ("a restore keeps the row counts", "  b.hist_valid = 0;\n}\n\n#endif", "}\n\n#endif"),
+    ("another order workspace inherits the row counts", "{ b.has_order_ws = 1; b.hist_valid = 0; }", "{ b.has_order_ws = 1; }"),
+    ("a failed launch after a conversion forgets that the mirror was rewritten",
+     "  if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }", "  if (p.converted == 1) { b.pk_valid = 1; }"),
 ]
 
 
@@ -84,22 +110,58 @@ def test_bookkeeping_sequences_under_sanitizers(tmp_path):
         assert "no violation" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
 
 
+def test_bookkeeping_state_space_walked_to_closure_under_sanitizers(tmp_path):
+    """Not sampled: a breadth-first walk of the abstract state space of the header -- every operation
+    with every parameter and every outcome of its internal choices from every reachable state, until no new state
+    appears; the invariants of the random driver after every transition. Prints how many states there are."""
+    import re
+    import time
+
+    exe = _build(CSRC, str(tmp_path / "bkcheck"))
+    t0 = time.time()
+    r = subprocess.run([exe, "--bfs"], capture_output=True, text=True, timeout=900)
+    dt = time.time() - t0
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "walked to closure" in r.stdout and "no violation" in r.stdout, r.stdout[-2000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    m = re.search(r"(\d+) reachable abstract states, (\d+) transitions", r.stdout)
+    states, edges = int(m.group(1)), int(m.group(2))
+    assert states > 100_000 and edges > 10_000_000, r.stdout[-600:]  # a walk that explores nothing proves nothing
+    print(r.stdout.strip().splitlines()[-1], f"({dt:.0f} s under ASan + UBSan)")
+
+
 def test_every_mutant_of_the_bookkeeping_is_caught(tmp_path):
+    """Each mutant must be caught by the random driver or, failing that, by the exhaustive walk (mutants are built without
+    the sanitizers: what is tested here is the harness, and 46 sanitizer builds would dominate the CPU suite)."""
     hdr = open(os.path.join(CSRC, "w2a_bookkeeping.h")).read()
-    missed = []
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    missed, by_walk = [], []
     for k, (name, old, new) in enumerate(MUTANTS):
         assert hdr.count(old) == 1, f"mutant {k} ({name}): its anchor text occurs {hdr.count(old)} times in the header"
         d = tmp_path / f"m{k}"
         d.mkdir()
         (d / "w2a_bookkeeping.h").write_text(hdr.replace(old, new))
-        exe = _build(str(d), str(d / "bkcheck"))
-        for seed in range(1, 9):  # most mutants die within the first few hundred sequences; the budget ones need rarer
-            r = subprocess.run([exe, "4000", "200", str(seed)], capture_output=True, text=True, timeout=600)  # set-ups
+        exe = str(d / "bkcheck")
+        r = subprocess.run([gxx, "-std=c++17", "-O2", "-Wall", f"-I{d}", SRC, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
+        caught = False
+        for seed in range(1, 4):  # most mutants die within the first few hundred sequences
+            r = subprocess.run([exe, "3000", "200", str(seed)], capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 assert "VIOLATION" in r.stdout, (name, r.stdout[-500:], r.stderr[-1500:])
+                caught = True
                 break
-        else:
+        if not caught:  # the walk sees every reachable state: what survives it is not observable at all
+            r = subprocess.run([exe, "--bfs"], capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                assert "VIOLATION" in r.stdout, (name, r.stdout[-500:], r.stderr[-1500:])
+                caught = True
+                by_walk.append(name)
+        if not caught:
             missed.append(name)
+    print(f"{len(MUTANTS)} mutants, {len(by_walk)} of them caught only by the exhaustive walk: {by_walk}")
     assert not missed, f"mutants the harness did not catch: {missed}"
 
 

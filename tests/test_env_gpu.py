@@ -1358,41 +1358,115 @@ def test_step_is_hipgraph_capturable(dev):
     assert (eager.state()["episode_no"] == 1).all() and torch.equal(eager.state()["t"], cap.state()["t"])
     eager.close()
     cap.close()
-    # A lock-step batch large enough for the 64-envs-per-wave kernel: eagerly it streams the packed state with the day
-    # as a kernel ARGUMENT -- which a graph replay would not advance. A captured w2a_step therefore runs the canonical
-    # kernel, and the handle keeps to the canonical form afterwards; results equal the eager (packed) env bit for bit.
+    # A lock-step batch large enough for the 64-envs-per-wave kernel streams the 16-B packed mirror of the state, whose day
+    # lives in device memory (one word per 64-env tile): a recorded packed step finds the right day on every replay, so
+    # a capture made on the packed form STAYS on it -- and the handle keeps that form current from then on (VERDICT r4
+    # item 4; the rules are csrc/w2a_bookkeeping.h: graph_packed, bk_end_call).
     from weather2alert_amd import _ffi
 
     n2, G2 = 131072 + 5, 6
     acts2 = [(torch.rand(n2, generator=g) < 0.25).to(torch.int32).to(dev) for _ in range(G2)]
     eager = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
     cap = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
+    q = lambda e, what: e._lib.w2a_query(e._h, what)  # noqa: E731
     eager.reset(seed=8)
     cap.reset(seed=8)
     eager.step(acts2[0])
-    cap.step(acts2[0])
+    cap.step(acts2[0])  # the eager warm-up step every capture needs anyway: the batch enters the packed form here
     assert eager.packed_state and cap.packed_state
-    cap.state()  # brings the canonical form up to date: a capture must not start on the packed form
     graph2 = torch.cuda.CUDAGraph()
-    ck = cap.state_dict()
     with torch.cuda.graph(graph2):
         for a in acts2:
             cap.step(a)
-    cap.load_state_dict(ck)
-    assert not cap.packed_state and cap._lib.w2a_query(cap._h, _ffi.Q_LOCKSTEP_DAY) == -1
-    for rep in range(3):
+    assert q(cap, _ffi.Q_LAST_STEP_KERNEL) == 2 and cap.packed_state  # recorded: k_step64 on the mirror
+    assert q(cap, _ffi.Q_LOCKSTEP_DAY) == -1 and q(cap, _ffi.Q_LOCKSTEP) == 1  # the day is the device's business now
+
+    def replay_and_compare():
         graph2.replay()
         for a in acts2:
             o, r, d, _, _ = eager.step(a)
         torch.cuda.synchronize()
-        assert eager.packed_state
+        assert torch.equal(cap._obs, o) and torch.equal(cap._reward, r) and torch.equal(cap._done_bool, d)
+
+    def same_state():
+        se, sc = eager.state(), cap.state()
+        for k in se:
+            assert torch.equal(se[k], sc[k]), k
+        assert cap.packed_state  # the read-back was a scratch copy: the mirror stays the primary form
+
+    for rep in range(3):
+        replay_and_compare()
+        assert eager.packed_state and cap.packed_state
+    same_state()
+    for a in acts2[:2]:  # eager steps on the captured handle: still the packed kernel
+        oc, rc, _, _, _ = cap.step(a)
+        oe, re_, _, _, _ = eager.step(a)
+        assert torch.equal(oc, oe) and torch.equal(rc, re_) and cap.last_step_kernel == "k_step64<packed>"
+    replay_and_compare()
+    # rollouts work on the canonical words and hand the state back to the mirror; the matrix-core kernel stays available
+    pol = dict(kind="threshold", feature="heat_qi", threshold=0.7, require_budget=True)
+    for e in (eager, cap):
+        e.rollout(pol, n_steps=3)
+    rc, re_ = cap.rollout(pol, n_steps=3), eager.rollout(pol, n_steps=3)
+    assert torch.equal(rc["alerts"], re_["alerts"]) and torch.equal(rc["return"], re_["return"])
+    assert cap.last_rollout_kernel == eager.last_rollout_kernel == "k_rollout_mfma" and cap.packed_state
+    replay_and_compare()
+    same_state()
+    # a whole-batch reset: new episodes, packed again before the call returns -- a replay may come right away
+    eager.reset(seed=9)
+    cap.reset(seed=9)
+    assert cap.packed_state and not eager.packed_state  # (the eager handle packs at its next step)
+    replay_and_compare()
+    # a masked reset ends lock step: the batch cannot be packed, the mirror is marked stale ON THE DEVICE, and a replay of
+    # the recorded packed steps does nothing but raise the status bit
+    m = np.arange(n2) % 5 == 0
+    cap.reset(seed=10, options={"mask": m})
+    eager.reset(seed=10, options={"mask": m})
+    assert not cap.packed_state and cap.check_status() == 0
+    before = (cap._obs.clone(), cap._reward.clone(), cap.state())
+    graph2.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="hipGraph"):
+        cap.check_status()
+    after = cap.state()
+    assert torch.equal(cap._obs, before[0]) and torch.equal(cap._reward, before[1])
+    for k in after:
+        assert torch.equal(after[k], before[2][k]), k
+    for a in acts2[:2]:  # eager steps go on, on the canonical words, identical to the other env
+        oc, rc, _, _, _ = cap.step(a)
+        oe, re_, _, _, _ = eager.step(a)
+        assert torch.equal(oc, oe) and torch.equal(rc, re_)
+    # ... until the next whole-batch reset makes the batch packable again
+    eager.reset(seed=11)
+    cap.reset(seed=11)
+    assert cap.packed_state
+    replay_and_compare()
+    assert cap.check_status() == 0 and eager.check_status() == 0
+    eager.close()
+    cap.close()
+    # A capture that starts on the canonical form (no eager step since the reset) records the canonical kernel -- no
+    # conversion is ever recorded -- and such a handle keeps to the canonical form for good.
+    eager = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
+    cap = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
+    eager.reset(seed=8)
+    cap.reset(seed=8)
+    graph3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph3):
+        for a in acts2:
+            cap.step(a)
+    assert q(cap, _ffi.Q_LAST_STEP_KERNEL) == 1 and not cap.packed_state
+    for rep in range(2):
+        graph3.replay()
+        for a in acts2:
+            o, r, d, _, _ = eager.step(a)
+        torch.cuda.synchronize()
         assert torch.equal(cap._obs, o) and torch.equal(cap._reward, r) and torch.equal(cap._done_bool, d)
     se, sc = eager.state(), cap.state()
     for k in se:
         assert torch.equal(se[k], sc[k]), k
-    cap.reset(seed=9)  # even after a full reset a captured handle stays on the canonical form
+    cap.reset(seed=9)
     cap.step(acts2[0])
-    assert not cap.packed_state
+    assert not cap.packed_state and cap.last_step_kernel == "k_step64"
     eager.close()
     cap.close()
 

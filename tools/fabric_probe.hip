@@ -29,6 +29,15 @@ struct u3 { uint32_t a, b, c; };
 __device__ const float *g_Z;
 __device__ const float4 *g_Wrt;
 #endif
+#ifdef PROBE_TABLE  // what-if: no coefficient-row gather. The table-sourced part of both logits comes as an
+                    // f32 pair from a day slice L[day][feature row][draw][2] (PROBE_TABLE=1; =2: one f32 per head from
+                    // two slices, the effectiveness one read by ~5 % of the envs) and the 4 run-time coefficients of both
+                    // heads from a compact [column * draws][8] f32 table (2.3 MB), both by lane = env
+__device__ const float *g_L;      // [153][R * 100][2]  (or two [153][R*100] planes)
+__device__ const float4 *g_W8;    // [S * 100][2] float4
+#define PT_DRAWS 100u
+#define PT_Y 11u
+#endif
 #ifdef PROBE_ONEPASS  // what-if: all 64 envs of the wave gathered in ONE pass of 8 rounds (two memory hops per wave
                       // instead of three, twice the gathered bytes in flight), one 64-env observation flush
 #define P_PASSES 1
@@ -74,6 +83,34 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
     acc = zz + wr.x * 0.5f + wr.y * 0.25f + wr.z * 0.125f + wr.w;
   }
 #endif
+#ifdef PROBE_TABLE
+  if (GATHER) {
+    // c.b = feature row, c.c = coefficient row (column * draws + draw); without augmentation column = county of the row
+    const uint32_t smp = c.c % PT_DRAWS, rows = (uint32_t)(
+#ifdef PROBE_LIB
+        g_rows_per_day
+#else
+        8206u
+#endif
+        );
+    const size_t day = (size_t)(n_raw >> 40);
+    const uint32_t li = c.b * PT_DRAWS + smp, wi = (c.b / PT_Y) * PT_DRAWS + smp;
+    const bool need = ((c.c * 2654435761u) >> 24) < 13u;  // ~5 % of the envs alert today with an open gate
+#if PROBE_TABLE == 1
+    const float2 l = reinterpret_cast<const float2 *>(g_L)[day * rows * PT_DRAWS + li];
+    acc += l.x + (need ? l.y : 0.f);
+#else
+    const float lb = g_L[day * rows * PT_DRAWS + li];
+    float le = 0.f;
+    if (need) le = g_L[(size_t)153 * rows * PT_DRAWS + day * rows * PT_DRAWS + li];
+    acc += lb + le;
+#endif
+    const float4 wb = g_W8[wi * 2];
+    float4 we = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (need) we = g_W8[wi * 2 + 1];
+    acc += wb.x * 0.5f + wb.y * 0.25f + wb.z * 0.125f + wb.w + we.x + we.y * 0.5f + we.z * 0.25f + we.w * 0.125f;
+  }
+#endif
   const int p = lane & 7, g = lane >> 3;
 #ifdef PROBE_DEP  // like k_step64: the gather indices are part of the streamed state (lane = env) and reach the
                   // 8-lanes-per-row mapping through LDS, so the gathers wait for the state loads
@@ -102,7 +139,7 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
 #ifdef PROBE_DEP
         const uint2 dd = desc[wave][pass * P_PASS_ENVS + r * 8 + g];
         x[r] = X[dd.x * 8 + p];
-#ifdef PROBE_ZSTREAM
+#if defined(PROBE_ZSTREAM) || defined(PROBE_TABLE)
         w[r] = x[r];
 #elif defined(PROBE_WDENSE)  // what-if: baseline coefficient rows on consecutive 128-B lines ([head][row][32] instead of
                              // [row][head][32], where they sit on every other line: half the L2 channels / sets)
@@ -284,6 +321,15 @@ int main() {
     CHECK(hipMalloc(&Z, (size_t)153 * n * 4)); CHECK(hipMalloc(&Wrt, n * 16));
     CHECK(hipMemset(Z, 0x3c, (size_t)153 * n * 4)); CHECK(hipMemset(Wrt, 0x3c, n * 16));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_Z), &Z, sizeof(Z))); CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_Wrt), &Wrt, sizeof(Wrt)));
+  }
+#endif
+#ifdef PROBE_TABLE
+  {
+    float *L; float4 *W8;
+    const size_t lbytes = (size_t)153 * R * 100 * 8;
+    CHECK(hipMalloc(&L, lbytes)); CHECK(hipMalloc(&W8, (size_t)S * 32));
+    CHECK(hipMemset(L, 0x3c, lbytes)); CHECK(hipMemset(W8, 0x3c, (size_t)S * 32));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_L), &L, sizeof(L))); CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_W8), &W8, sizeof(W8)));
   }
 #endif
   uint32_t *hw = (uint32_t *)malloc(n * 4), *hx = (uint32_t *)malloc(n * 4);

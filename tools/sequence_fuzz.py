@@ -122,9 +122,10 @@ class Runner:
         self.state_every_op = i % 2 == 0
         self.log[0] += f"; state after every op: {self.state_every_op}"
         self.ckpt = None
-        self.graph_done = False
+        self.graph = None
         self.stats = {"ops": 0, "steps": 0, "resets": 0, "rollouts": 0, "graphs": 0, "ckpt": 0, "worst": 0.0,
-                      "packed_steps": 0, "mfma_rollouts": 0, "after_done": 0, "autoresets": 0}
+                      "packed_steps": 0, "mfma_rollouts": 0, "after_done": 0, "autoresets": 0, "packed_graphs": 0,
+                      "replays": 0, "stale_replays": 0}
         self.expect_status = 0
 
     # ------------------------------------------------------------------ checking
@@ -141,6 +142,11 @@ class Runner:
             self.fail(f"{where}: handle claims lock-step day {d}, the envs are at {m.lockstep_truth()} (-1 = not in lock step)")
         if d != m.known_day:
             self.fail(f"{where}: W2A_Q_LOCKSTEP_DAY {d}, the sequence implies {m.known_day}")
+        lk = self.q(_ffi.Q_LOCKSTEP)
+        if lk and not m.uniform_truth():
+            self.fail(f"{where}: handle claims lock step, the envs are not on one day")
+        if lk != int(m.lock):
+            self.fail(f"{where}: W2A_Q_LOCKSTEP {lk}, the sequence implies {int(m.lock)}")
         if e.packed_state != m.packed_current:
             self.fail(f"{where}: packed_state {e.packed_state}, the sequence implies {m.packed_current}")
         if self.q(_ffi.Q_LAST_STEP_KERNEL) != m.last_step_kernel:
@@ -170,6 +176,10 @@ class Runner:
             bits = 2 | (4 if (want & 4) else 0)  # raised for the bad action; other bits were cleared with it
             if not (want & 2):
                 self.fail(f"{where}: BAD_ACTION raised, not expected")
+            return
+        except RuntimeError:  # W2A_ST_STALE_GRAPH: a replayed packed step found its mirror poisoned
+            if not (want & 8) or (want & 2):
+                self.fail(f"{where}: STALE_GRAPH raised, status word wanted {want}")
             return
         if bits != want:
             self.fail(f"{where}: status word {bits}, want {want}")
@@ -347,7 +357,7 @@ class Runner:
         self.log.append(f"state(); w2a_invalidate(); {'w2a_set_budget_bound(max)' if tell else '(budget bound left unknown)'}")
         st = self.check_state("state() before w2a_invalidate")
         e = self.env
-        _ffi.check(e._lib.w2a_invalidate(e._h), "w2a_invalidate")
+        _ffi.check(e._lib.w2a_invalidate(e._h, e._stream()), "w2a_invalidate")
         self.m.note_invalidate()
         if tell:
             b = int(max(int(st["budget"].max()), int(st["sticky_budget"].max()), 0))
@@ -380,7 +390,10 @@ class Runner:
                 self.log.append("C level: w2a_sort_episodes (already sorted: the identity)")
                 _ffi.check(e._lib.w2a_sort_episodes(e._h, e._sort_ws.data_ptr(), e._sort_ws.numel(), e._stream()),
                            "w2a_sort_episodes")
-                m.rm_valid, m.packed_current = False, False
+                m.rm_valid = False  # bk_sort + bk_end_call
+                m._ensure_canonical()
+                m._canonical_modified()
+                m._end_call()
             else:
                 self.log.append("C level: w2a_reset_device_rng(mask = nobody)")
                 zero = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
@@ -399,34 +412,57 @@ class Runner:
 
     def op_graph(self):
         """A block of K step() calls captured into a hipGraph and replayed R times (autoreset in the kernel or disabled:
-        the host must have nothing to do between the steps of a replayed block)."""
+        the host must have nothing to do between the steps of a replayed block). Whatever form of the state the handle
+        steps right now is the form the recorded kernels step -- the packed one too (round 5): the capture executes
+        nothing and the handle keeps the recorded form current from then on, so the sequence simply goes on afterwards
+        (more replays come as their own operation, after whatever else the sequence does to the handle)."""
         rng, n, e, m = self.rng, self.n, self.env, self.m
         K, R = int(rng.integers(1, 5)), int(rng.integers(1, 4))
         acts = [(rng.random(n) < 0.3).astype(np.int64) for _ in range(K)]
         at = [torch.as_tensor(a, device=self.dev).to(torch.int32) for a in acts]
+        if rng.random() < 0.5 and not m.pending_reset:
+            self.op_step()  # a batch that can be packed enters the packed form here: the capture then records packed steps
+            self.after_op()
         self.log.append(f"hipGraph: capture {K} steps, replay {R} times")
         where = self.log[-1]
-        self.check_state(where + " [state() before capture]")  # canonical form: a capture must not start on the packed one
-        ck, mk = e.state_dict(), m.snapshot()
-        known, lsk, bnd = m.known_day, m.last_step_kernel, (m.bound, m.bound_known)
+        self.check_state(where + " [state() before capture]")  # either form may be recorded, but no conversion: both current now
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for t in at:
                 e.step(t)
         # what the capture calls did to the handle's bookkeeping (no kernel ran): mirrored by stepping the model's flags
-        for _ in range(K):
-            m._note_step(m._mode() in ("dev_same", "dev_next"), capturing=True)
-        e.load_state_dict(ck)
-        m.restore(mk)
-        del known, lsk, bnd
-        self.check_flags(where + " [after capture + restore]")
+        kinds = [m._note_step(m._mode() in ("dev_same", "dev_next"), capturing=True) for _ in range(K)]
+        if min(kinds) < 0 or len(set(kinds)) != 1:
+            self.fail(f"{where}: the model expects the capture to be refused / to mix kernels: {kinds}")
+        self.log[-1] += f" (recorded kernel {kinds[0]})"
+        self.graph = dict(g=g, acts=acts, at=at, kind=kinds[0], mode=m._mode(), step_kernel=m.step_kernel, write_obs=m.write_obs)
+        self.check_flags(where + " [after capture]")
+        self.stats["graphs"] += 1
+        self.stats["packed_graphs"] += kinds[0] == 2
         for rep in range(R):
-            g.replay()
-            for a in acts:
-                exp = m.step(a, None)
-                self.expect_status |= exp["status"]
-            # a replay advances the device behind the host: mirror only the arithmetic; the handle's flags stay
+            self.op_replay()
+
+    def op_replay(self):
+        """One more replay of the recorded block -- after whatever the sequence did to the handle since the capture."""
+        e, m, G = self.env, self.m, self.graph
+        self.log.append(f"hipGraph: replay ({len(G['acts'])} recorded steps, kernel {G['kind']})")
+        where = self.log[-1]
+        G["g"].replay()
         torch.cuda.synchronize()
+        if G["kind"] == 2 and m.poisoned:
+            # the mirror could not be kept current: the replayed packed steps do nothing but raise W2A_ST_STALE_GRAPH
+            self.log[-1] += " -> poisoned mirror: nothing stepped"
+            self.expect_status |= 8
+            self.stats["stale_replays"] += 1
+            if self.state_every_op:
+                return
+            self.check_state(where + " [state after a refused replay]")
+            return
+        if G["kind"] == 2 and not m.pk_valid:
+            self.fail(f"{where}: model: a recorded packed step on a mirror that is neither current nor poisoned")
+        for a in G["acts"]:
+            exp = m.step(a, None, note=False)
+            self.expect_status |= exp["status"]
         rd = e._reward.cpu().numpy()
         err = np.abs(rd.astype(np.float64) - exp["reward"])
         if err.max() > REWARD_TOL:
@@ -434,9 +470,13 @@ class Runner:
         if not np.array_equal(e._done_bool.cpu().numpy(), exp["done"]):
             self.fail(f"{where}: done after the last replayed step differs")
         self.check_final(where)
-        self.graph_done = True
-        self.stats["graphs"] += 1
-        self.stats["steps"] += K * R
+        self.stats["steps"] += len(G["acts"])
+        self.stats["replays"] += 1
+
+    def replay_possible(self) -> bool:
+        G, m = self.graph, self.m
+        return (G is not None and not m.pending_reset and m._mode() == G["mode"] and m.step_kernel == G["step_kernel"]
+                and m.write_obs == G["write_obs"])
 
     # ------------------------------------------------------------------ sequence
     def run(self):
@@ -456,8 +496,10 @@ class Runner:
                 ops += [("reset_masked", 5), ("tuples", 3), ("tuples_masked", 3)]
             if self.ckpt is not None:
                 ops.append(("restore", 3))
-            if not self.graph_done and not m.pm and m._mode() in ("dev_same", "dev_next", "none") and not m.pending_reset:
-                ops.append(("graph", 2))
+            if self.graph is None and not m.pm and m._mode() in ("dev_same", "dev_next", "none") and not m.pending_reset:
+                ops.append(("graph", 3))
+            if self.replay_possible():
+                ops.append(("replay", 5))
             names, w = zip(*ops)
             op = str(rng.choice(names, p=np.asarray(w, float) / sum(w)))
             if op == "step":
@@ -488,6 +530,8 @@ class Runner:
                 self.op_invalidate()
             elif op == "graph":
                 self.op_graph()
+            elif op == "replay":
+                self.op_replay()
             elif op == "switch":
                 self.op_switch_kernel()
             elif op == "c_reset":

@@ -83,6 +83,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = f"{LIB}.{os.getpid()}.tmp"  # several ranks may build at once: private temp + atomic rename
+    # what is about to be compiled, hashed BEFORE the compiler reads it: an edit during the compile then leaves a sidecar
+    # that does not match the tree, and the next needs_build() rebuilds
+    src_hash = build_hash()
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INC}", SRC,
            "-o", tmp]
     cmd += os.environ.get("W2A_CXXFLAGS", "").split()  # e.g. -DLANES=8 for kernel-geometry A/B runs
@@ -94,10 +97,16 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     if verbose:
         print(r.stderr)
+    # sidecar away first, library in, sidecar back: at no moment does an OLD sidecar stand beside the NEW library (or
+    # the other way round) claiming it current -- a crash in between leaves a library without sidecar = file-time rule
+    try:
+        os.remove(HASH_FILE)
+    except OSError:
+        pass
     os.replace(tmp, LIB)
     htmp = f"{HASH_FILE}.{os.getpid()}.tmp"
     with open(htmp, "w") as f:
-        f.write(build_hash() + "\n")
+        f.write(src_hash + "\n")
     os.replace(htmp, HASH_FILE)
     return LIB
 

@@ -67,15 +67,20 @@ struct StateArrays {
   u3 *hot3;
   u3 *stepc;
   // lock-step mirror of hot3 / stepc, 8 + 8 B per env (k_step64's packed variant streams 20 B in and 8 B out per
-  // env-step instead of 28 and 12). In lock step the day t, the episode length and -- until the terminal step -- the
-  // `finished` bit are the same for every env and travel as kernel arguments:
+  // env-step instead of 28 and 12). In lock step the day t and the episode length are the same for every env: the
+  // length (a table constant) travels as a kernel argument, the day lives in ONE word per 64-env tile (pk_day: read
+  // and advanced by the wave that owns the tile, 4 B per 64 envs) -- in device memory, so that a step recorded into a
+  // hipGraph finds the right day on every replay:
   //   pk_hot.x: used[0:8) streak[8:16) hist14[16:30) finished[30]      pk_hot.y: episode return (f32 bits)
   //   pk_c.x:   budget[0:16) coef_col[16:32)                            pk_c.y:   ep_row[0:22) sample[22:32)
+  //   pk_day[tile]: the day of envs 64 tile .. 64 tile + 63, or W2A_PK_DAY_POISON (w2a_bookkeeping.h, graph_packed)
   // (last_actual = hist14 & 1; at_budget is derived). Valid for T <= 255, S < 65536, n_samples <= 1024,
   // S_w * Y < 2^22, budgets <= 65535 -- checked on the host, which also tracks which of the two forms is current.
   uint2 *pk_hot;
   uint2 *pk_c;
+  uint32_t *pk_day;
 };
+#define W2A_PK_DAY_POISON 0xFFFFFFFFu
 #define PK_USED(w) ((w) & 255u)
 #define PK_STREAK(w) (((w) >> 8) & 255u)
 #define PK_HIST(w) (((w) >> 16) & 0x3FFFu)
@@ -184,7 +189,10 @@ struct w2a_env {
   const float *xs;
   const void *xmax_ws;   // workspace whose slot maxima (once-per-table scan) are valid
   // matrix-core rollout (w2a_rollout_mfma.hip.h): tile list by feature row + digit table of W, in its own workspace
-  const uint32_t *order_cursor;  // the counting sort's cursors after the scatter (end of every feature row's segment)
+  // order workspace (w2a_rollout_order_attach / w2a_rollout_order): envs per feature row, each env's rank inside its row,
+  // first position and first 64-env tile of every row (rows + 1 entries each)
+  void *order_ws;
+  uint32_t *order_cnt, *order_rank, *order_start, *order_tile_start;
   const void *rm_ws;             // workspace whose W digit table is built
   const uint4 *rm_tiles;
   const uint32_t *rm_n_tiles;

@@ -126,12 +126,13 @@ const char *w2a_last_error(void) { return g_err; }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// header (slot map) + cold 16 B + hot3 12 B + stepc 12 B per env, every array on its own 256-B boundary (for odd
-// env counts the 12-B arrays would otherwise start at a 4-B boundary and their 12-B loads straddle lines)
+// header (slot map) + cold 16 B + hot3 12 B + stepc 12 B per env + the lock-step mirror (8 + 8 B per env, one day word
+// per 64-env tile), every array on its own 256-B boundary (for odd env counts the 12-B arrays would otherwise start at a
+// 4-B boundary and their 12-B loads straddle lines)
 size_t w2a_state_bytes(int64_t num_envs) {
   if (num_envs <= 0) return 0;
   const size_t n = (size_t)num_envs;
-  return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n) + 2 * align256(8 * n);
+  return HDR_BYTES + align256(16 * n) + 2 * align256(12 * n) + 2 * align256(8 * n) + align256(4 * ((n + 63) / 64));
 }
 
 // ---- which form of the step state is current (StateArrays::pk_hot / pk_c): decided in w2a_bookkeeping.h; this is its
@@ -142,10 +143,19 @@ struct HipDev {
   void pack_state() {
     hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n);
   }
-  void unpack_state(int32_t t, int32_t n_days) {
-    hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, t, n_days);
+  void unpack_state(int32_t n_days) {
+    hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, n_days);
+  }
+  void poison_mirror() {
+    const int64_t tiles = (env->n + 63) / 64;
+    hipLaunchKernelGGL(k_poison_mirror, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, env->st, env->n);
   }
 };
+// end of an entry point that may have changed which form of the state is current (w2a_bookkeeping.h: bk_end_call)
+static void end_call(w2a_env *env, hipStream_t s) {
+  HipDev d{env, s};
+  bk_end_call(env->bk, d);
+}
 static void ensure_canonical(w2a_env *env, hipStream_t s) {
   HipDev d{env, s};
   bk_ensure_canonical(env->bk, d);
@@ -216,6 +226,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.stepc = reinterpret_cast<u3 *>((char *)h->st.hot3 + align256(12 * (size_t)num_envs));
   h->st.pk_hot = reinterpret_cast<uint2 *>((char *)h->st.stepc + align256(12 * (size_t)num_envs));
   h->st.pk_c = reinterpret_cast<uint2 *>((char *)h->st.pk_hot + align256(8 * (size_t)num_envs));
+  h->st.pk_day = reinterpret_cast<uint32_t *>((char *)h->st.pk_c + align256(8 * (size_t)num_envs));
   bk_init(h->bk, t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22), -1, 0);
   h->status = status;
   h->has_autoreset = 0;
@@ -224,13 +235,15 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->prep = nullptr;
   h->pm_kernel = W2A_PM_VECTOR;
   h->xmax_ws = nullptr;
-  h->order_cursor = nullptr; h->rm_ws = nullptr;
+  h->order_ws = nullptr; h->order_cnt = h->order_rank = h->order_start = h->order_tile_start = nullptr; h->rm_ws = nullptr;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
   hipError_t e2 = hipMemset(status, 0, sizeof(int32_t));
   if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: header upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
   int64_t blocks = (num_envs + 255) / 256;
   hipLaunchKernelGGL(k_init_state, dim3((unsigned)blocks), dim3(256), 0, 0, h->st, num_envs);
+  hipError_t e0 = hipGetLastError();
+  if (e0 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: k_init_state launch failed: %s", hipGetErrorString(e0)); }
   // header word 32: scratch for the one-off scan of the coefficient rows (see k_scan_tail_slots)
   int32_t *scan_flag = reinterpret_cast<int32_t *>(state) + ROWF;
   const int64_t w_rows = (int64_t)t->S * t->n_samples * 2;
@@ -272,8 +285,13 @@ static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
+  if (env->bk.hist_valid && a.from_tuples != 2) {  // whole-batch reset, order workspace attached: row counts and per-env ranks come with it
+    HIP_TRY(hipMemsetAsync(env->order_cnt, 0, 4 * (size_t)env->tb.S_w * env->tb.Y, (hipStream_t)stream));
+    a.order_cnt = env->order_cnt; a.order_rank = env->order_rank;
+  }
   hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
+  end_call(env, (hipStream_t)stream);
   return W2A_OK;
 }
 
@@ -366,6 +384,7 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  end_call(env, s);
   return W2A_OK;
 }
 
@@ -498,6 +517,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
     else hipLaunchKernelGGL(k_posterior_mean_v<7>, dim3(grid), dim3(PMV_THREADS), 0, (hipStream_t)stream, a);
   }
   HIP_TRY(hipGetLastError());
+  end_call(env, (hipStream_t)stream);
   return W2A_OK;
 }
 
@@ -530,26 +550,50 @@ int w2a_set_semantics(w2a_env *env, uint32_t fixes) {
 
 size_t w2a_rollout_order_workspace_bytes(int64_t num_envs, int64_t table_rows) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll) return 0;
-  return align256(4 * (size_t)num_envs) + align256(4 * (size_t)table_rows);
+  return 2 * align256(4 * (size_t)num_envs) + align256(4 * (size_t)table_rows) + 2 * align256(4 * ((size_t)table_rows + 1));
+}
+
+static int order_attach(w2a_env *env, void *workspace, size_t workspace_bytes, const char *who) {
+  const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
+  if (workspace_bytes < w2a_rollout_order_workspace_bytes(env->n, rows)) return fail(W2A_ERR_STATE, "%s: workspace too small", who);
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "%s: workspace must be 256-B aligned", who);
+  if (env->order_ws == workspace) return W2A_OK;
+  const size_t n = (size_t)env->n;
+  char *p = (char *)workspace;
+  uint32_t *order = (uint32_t *)p;         p += align256(4 * n);
+  env->order_rank = (uint32_t *)p;         p += align256(4 * n);
+  env->order_cnt = (uint32_t *)p;          p += align256(4 * (size_t)rows);
+  env->order_start = (uint32_t *)p;        p += align256(4 * ((size_t)rows + 1));
+  env->order_tile_start = (uint32_t *)p;
+  env->order_ws = workspace;
+  // the order of an earlier workspace stays a valid permutation; this one holds none yet
+  if (env->order && env->order != order) { env->order = nullptr; env->bk.has_order = 0; env->bk.rm_valid = 0; }
+  bk_order_attach(env->bk);
+  return W2A_OK;
+}
+
+int w2a_rollout_order_attach(w2a_env *env, void *workspace, size_t workspace_bytes) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_order_attach: NULL argument");
+  return order_attach(env, workspace, workspace_bytes, "w2a_rollout_order_attach");
 }
 
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_order: NULL argument");
+  const int rc = order_attach(env, workspace, workspace_bytes, "w2a_rollout_order");
+  if (rc) return rc;
   const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
-  if (workspace_bytes < w2a_rollout_order_workspace_bytes(env->n, rows)) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace too small");
-  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_order: workspace must be 256-B aligned");
   const size_t n = (size_t)env->n;
-  char *p = (char *)workspace;
-  uint32_t *order = (uint32_t *)p; p += align256(4 * n);  // stays in use after the call
-  uint32_t *cnt = (uint32_t *)p;
+  uint32_t *order = (uint32_t *)workspace;  // stays in use after the call
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)rows, s));
-  hipLaunchKernelGGL(k_order_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, cnt, env->n);
-  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, s, cnt, (int32_t)rows);
-  hipLaunchKernelGGL(k_order_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.cold, cnt, order, env->n);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (!env->bk.hist_valid) {  // the last whole-batch reset did not leave the counts (or something re-drew episodes since)
+    HIP_TRY(hipMemsetAsync(env->order_cnt, 0, 4 * (size_t)rows, s));
+    hipLaunchKernelGGL(k_order_rank, dim3(blocks), dim3(256), 0, s, env->st.cold, env->order_cnt, env->order_rank, env->n);
+  }
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, s, env->order_cnt, (int32_t)rows, env->order_start, env->order_tile_start);
+  hipLaunchKernelGGL(k_order_place, dim3(blocks), dim3(256), 0, s, env->st.cold, env->order_start, env->order_rank, order, env->n);
   HIP_TRY(hipGetLastError());
   env->order = order;
-  env->order_cursor = cnt;
   bk_order_set(env->bk);
   return W2A_OK;
 }
@@ -559,7 +603,7 @@ static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 63) /
 size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0) return 0;
   const size_t w_rows = (size_t)S * n_samples * 2;
-  return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 + 2 * align256(4 * (size_t)table_rows) +
+  return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 +
          align256(w_rows * ROWF * 4) + align256(w_rows * 4) + align256(2 * w_rows) + 3 * 256;
 }
 
@@ -569,14 +613,12 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
   if (workspace_bytes < w2a_rollout_mfma_workspace_bytes(env->n, rows, env->tb.S, env->tb.n_samples))
     return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace must be 256-B aligned");
-  if (!env->order || !env->order_cursor)
+  if (!env->order || !env->order_start)
     return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: call w2a_rollout_order for this episode first");
   const size_t w_rows = (size_t)env->tb.S * env->tb.n_samples * 2;
   char *p = (char *)workspace;
   uint4 *tiles = (uint4 *)p;            p += align256(16 * rm_max_tiles(env->n, rows));
   uint32_t *n_tiles = (uint32_t *)p;    p += 256;
-  uint32_t *seg_start = (uint32_t *)p;  p += align256(4 * (size_t)rows);
-  uint32_t *seg_end = (uint32_t *)p;    p += align256(4 * (size_t)rows);
   uint32_t *wq = (uint32_t *)p;         p += align256(w_rows * ROWF * 4);
   float *wscale = (float *)p;           p += align256(w_rows * 4);
   uint32_t *rowflag = (uint32_t *)p;    p += align256(2 * w_rows);
@@ -595,10 +637,10 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
     HIP_TRY(hipGetLastError());
     env->rm_ws = workspace;
   }
-  // tiles of <= 64 consecutive positions of the visiting order that share one feature row
-  hipLaunchKernelGGL(k_rm_bounds, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, env->order_cursor, (int32_t)rows,
-                     seg_start, seg_end);
-  hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, s, seg_start, seg_end, (int32_t)rows, tiles, n_tiles, 64u);
+  // tiles of <= 64 consecutive positions of the visiting order that share one feature row: one thread per row, from the
+  // row starts / tile starts the order's scan left in its workspace
+  hipLaunchKernelGGL(k_rm_tiles, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, env->order_start, env->order_tile_start,
+                     (int32_t)rows, tiles, n_tiles);
   HIP_TRY(hipGetLastError());
   env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq; env->rm_wscale = wscale; env->rm_rowflag = rowflag;
   env->rm_xs = xs;
@@ -633,10 +675,10 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
   a.order = env->order;
   hipStream_t s = (hipStream_t)stream;
   HipDev dv{env, s};
-  // -1: the handle does not know every env to be on the same day. A batch in lock step stays in lock step: every env
-  // runs the same n_steps days, or all of them reach their last day
-  const int32_t lockstep_day = bk_rollout_begin(env->bk, dv, n_steps);
-  const int rkernel = bk_rollout_kernel(env->bk, lockstep_day, env->tb.fixes != 0, W2A_ROLLOUT_MFMA != 0, W2A_ROLLOUT_WIDE != 0);
+  // does the handle know every env to be on the same day? A batch in lock step stays in lock step: every env runs the
+  // same n_steps days, or all of them reach their last day
+  const bool lock = bk_rollout_begin(env->bk, dv, n_steps);
+  const int rkernel = bk_rollout_kernel(env->bk, lock, env->tb.fixes != 0, W2A_ROLLOUT_MFMA != 0, W2A_ROLLOUT_WIDE != 0);
   if (alert_mask) HIP_TRY(hipMemsetAsync(alert_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (attempt_mask) HIP_TRY(hipMemsetAsync(attempt_mask, 0, (size_t)env->n * mask_words * sizeof(uint32_t), s));
   if (rkernel == W2A_BK_ROLLOUT_MFMA) {
@@ -648,10 +690,12 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());
+    end_call(env, s);
     return W2A_OK;
   }
   launch_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, env->tb.fixes != 0, grid_for(env->n), s, a);
   HIP_TRY(hipGetLastError());
+  end_call(env, s);
   return W2A_OK;
 }
 
@@ -704,11 +748,13 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
     const unsigned grid8 = (unsigned)((max_tiles_i8(env->n, env->tb.S) + 7) / 8 * 8);
     hipLaunchKernelGGL(k_pm_rollout_i8, dim3(grid8), dim3(PI8_THREADS), 0, s, ia);
     HIP_TRY(hipGetLastError());
+    end_call(env, s);
     return W2A_OK;
   }
   const unsigned grid = (unsigned)((max_tiles(env->n, env->tb.S) + 7) / 8 * 8);
   launch_pm_rollout(policy->kind, alert_mask || attempt_mask || ret_snapshot, grid, s, pa);
   HIP_TRY(hipGetLastError());
+  end_call(env, s);
   return W2A_OK;
 }
 
@@ -736,6 +782,7 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
   ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_policy_actions, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
+  end_call(env, (hipStream_t)stream);
   return W2A_OK;
 }
 
@@ -745,6 +792,7 @@ int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
   ensure_canonical(env, (hipStream_t)stream);
   hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->st, env->n, env->tb.Y, env->tb.n_samples, *view);
   HIP_TRY(hipGetLastError());
+  end_call(env, (hipStream_t)stream);
   return W2A_OK;
 }
 
@@ -752,6 +800,7 @@ int w2a_query(w2a_env *env, int what) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_query: NULL handle");
   switch (what) {
     case W2A_Q_LOCKSTEP_DAY: return env->bk.uni_t;
+    case W2A_Q_LOCKSTEP: return env->bk.lock;
     case W2A_Q_PACKED_ELIGIBLE: return bk_packed_eligible(env->bk) ? 1 : 0;
     case W2A_Q_PACKED_CURRENT: return env->bk.pk_valid;
     case W2A_Q_CANONICAL_CURRENT: return env->bk.canon_valid;
@@ -770,22 +819,40 @@ __global__ void k_budget_scan(StateArrays st, int64_t n, int32_t *out) {
   if ((threadIdx.x & 63) == 0 && b > 0) atomicMax(out, b);
 }
 
-int w2a_invalidate(w2a_env *env) {
+int w2a_invalidate(w2a_env *env, void *stream) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
-  bk_invalidate(env->bk);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(W2A_ERR_STATE, "w2a_invalidate: the stream is recording a hipGraph (the call waits for the stream and "
+                                 "reads a value back)");
+    (void)hipGetLastError();
+  }
   // What was known about budgets described another buffer, and the restored one may hold budgets -- sticky ones too --
   // that no later reset argument will ever mention. The handle reads them itself: a rare call (checkpoint restore), so it
-  // may wait for whatever the caller used to write the buffer (found by tools/sequence_fuzz.py, seed 99 sequence 77: a
-  // caller's bound stated after a later w2a_reset covered the new budgets only, a restored sticky budget of 65 721 then
-  // reached the 16-bit packed form)
-  HIP_TRY(hipDeviceSynchronize());
+  // may wait for `stream` -- the stream the caller wrote the buffer on -- and for nothing else (found by
+  // tools/sequence_fuzz.py, seed 99 sequence 77: a caller's bound stated after a later w2a_reset covered the new budgets
+  // only, a restored sticky budget of 65 721 then reached the 16-bit packed form)
   int32_t *d_max = reinterpret_cast<int32_t *>(const_cast<int32_t *>(env->slot_obs)) + ROWF + 1;  // header scratch word 33
   int32_t h_max = 0;
-  HIP_TRY(hipMemcpy(d_max, &h_max, sizeof(h_max), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_budget_scan, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, 0, env->st, env->n, d_max);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost));
-  bk_set_budget_bound(env->bk, (int64_t)h_max);  // the first statement after bk_invalidate: taken as covering everything
+  hipError_t e = hipMemsetAsync(d_max, 0, sizeof(int32_t), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_budget_scan, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, d_max);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  // whatever happened above, the handle no longer trusts anything it derived from the old buffer
+  bk_invalidate(env->bk);
+  if (e != hipSuccess) {
+    end_call(env, s);
+    return fail(W2A_ERR_HIP, "w2a_invalidate: scanning the restored buffer failed (budgets stay unknown: the packed "
+                             "form is off until w2a_set_budget_bound): %s", hipGetErrorString(e));
+  }
+  // restored budgets below zero are clamped by the reset kernels the same way (draw_episode: b < 0 -> 0)
+  bk_set_budget_bound(env->bk, (int64_t)(h_max > 0 ? h_max : 0));  // the first statement after bk_invalidate: taken as covering everything
+  end_call(env, s);
   return W2A_OK;
 }
 

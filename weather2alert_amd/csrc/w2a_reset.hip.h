@@ -19,6 +19,10 @@ struct ResetArgs {
   ResetCfg rc;
   int32_t from_tuples;  // 0: device RNG draw, 1: caller's tuples, 2: observe only (state untouched)
   int32_t restart;      // device RNG draw: 1 = the per-env episode counter restarts at 0 (explicit re-seed)
+  // whole-batch resets of a handle with an attached order workspace (w2a_rollout_order_attach; both NULL otherwise): envs
+  // per feature row (zeroed by the caller before the launch) and each env's position inside its row -- the first pass
+  // of the visiting order's counting sort (w2a_rollout.hip.h), one returning atomic per env behind the observation stores
+  uint32_t *order_cnt, *order_rank;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     }
     if (bad & 1) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
     if (bad & 4) atomicOr(a.status, (int)W2A_ST_STEP_AFTER_DONE);
+    if (a.order_cnt) a.order_rank[e] = atomicAdd(&a.order_cnt[ep.ep_row], 1u);
   }
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }

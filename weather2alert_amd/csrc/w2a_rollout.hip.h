@@ -34,33 +34,48 @@ struct RolloutArgs {
                                   // fabric traffic per 1 M-env episode, profiles/r02/rollout_counters.log)
 };
 
-// visiting order = counting sort of the env ids by feature row (cold.x = county_w * Y + year_i): histogram, scan,
-// scatter. The order inside a row is whatever the atomics give -- any permutation is correct, see above.
-__global__ void k_order_hist(const uint4 *cold, uint32_t *cnt, int64_t n) {
+// visiting order = counting sort of the env ids by feature row (cold.x = county_w * Y + year_i). The order inside a row
+// is whatever the atomics give -- any permutation is correct, see above.
+//   count + rank   cnt[row] = envs of the row, rank[env] = the env's position inside its row: ONE returning atomic per env.
+//                  A whole-batch k_reset does this itself when an order workspace is attached (w2a_rollout_order_attach:
+//                  it holds the env's row anyway and the atomic hides behind its observation stores); k_order_rank is
+//                  the same pass for every other case (first use, masked resets, in-kernel autoresets, restores)
+//   scan           start[row] = first position of the row (exclusive scan of cnt, start[rows] = n) and, in the same pass,
+//                  tile_start[row] = first 64-env tile of the row (exclusive scan of ceil(cnt / 64)): the matrix-core
+//                  rollout's tile list needs no pass of its own (k_rm_tiles)
+//   place          order[start[row] + rank[env]] = env: no atomics
+// (Until round 4: histogram atomics, scan, a second pass of returning atomics for the scatter, and a one-workgroup tile
+// list: 47 + 8 + 49 + 5 + 24 us per 1 M-env episode, profiles/r04/kernel_trace_rollout_bench.txt.)
+__global__ void k_order_rank(const uint4 *cold, uint32_t *cnt, uint32_t *rank, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&cnt[cold[i].x], 1u);
+  if (i < n) rank[i] = atomicAdd(&cnt[cold[i].x], 1u);
 }
-__global__ __launch_bounds__(1024) void k_order_scan(uint32_t *cnt, int32_t rows) {  // one workgroup, exclusive, in place
-  __shared__ uint32_t s_sum[1024];
+__global__ __launch_bounds__(1024) void k_order_scan(const uint32_t *cnt, int32_t rows, uint32_t *start, uint32_t *tile_start) {
+  __shared__ uint32_t s_sum[1024], s_til[1024];  // one workgroup
   const int tid = threadIdx.x;
   const int chunk = (rows + 1023) / 1024;
   const int r0 = min(rows, tid * chunk), r1 = min(rows, r0 + chunk);
-  uint32_t mine = 0;
-  for (int r = r0; r < r1; ++r) mine += cnt[r];
-  s_sum[tid] = mine;
+  uint32_t mine = 0, mine_t = 0;
+  for (int r = r0; r < r1; ++r) { const uint32_t c = cnt[r]; mine += c; mine_t += (c + 63u) >> 6; }
+  s_sum[tid] = mine; s_til[tid] = mine_t;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
-    const uint32_t v = tid >= d ? s_sum[tid - d] : 0u;
+    const uint32_t v = tid >= d ? s_sum[tid - d] : 0u, w = tid >= d ? s_til[tid - d] : 0u;
     __syncthreads();
-    s_sum[tid] += v;
+    s_sum[tid] += v; s_til[tid] += w;
     __syncthreads();
   }
-  uint32_t run = s_sum[tid] - mine;
-  for (int r = r0; r < r1; ++r) { const uint32_t c = cnt[r]; cnt[r] = run; run += c; }
+  uint32_t run = s_sum[tid] - mine, run_t = s_til[tid] - mine_t;
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t c = cnt[r];
+    start[r] = run; tile_start[r] = run_t;
+    run += c; run_t += (c + 63u) >> 6;
+  }
+  if (tid == 1023) { start[rows] = s_sum[1023]; tile_start[rows] = s_til[1023]; }
 }
-__global__ void k_order_scatter(const uint4 *cold, uint32_t *cursor, uint32_t *order, int64_t n) {
+__global__ void k_order_place(const uint4 *cold, const uint32_t *start, const uint32_t *rank, uint32_t *order, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) order[atomicAdd(&cursor[cold[i].x], 1u)] = (uint32_t)i;
+  if (i < n) order[start[cold[i].x] + rank[i]] = (uint32_t)i;
 }
 
 // the built-in policies on what the reference's agent would see (shared by k_rollout and k_policy_actions)

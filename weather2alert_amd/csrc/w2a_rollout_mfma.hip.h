@@ -74,12 +74,15 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
   }
   wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
 }
-// feature-row segments of the visiting order from the counting sort's cursors (cursor[r] = end of row r after the scatter)
-__global__ void k_rm_bounds(const uint32_t *cursor, int32_t rows, uint32_t *start, uint32_t *end) {
+// the tile list: <= 64 consecutive positions of the visiting order that share one feature row; one thread per row, from
+// the row starts and tile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)
+__global__ void k_rm_tiles(const uint32_t *start, const uint32_t *tile_start, int32_t rows, uint4 *tiles, uint32_t *n_tiles) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) *n_tiles = tile_start[rows];
   if (r >= rows) return;
-  start[r] = r ? cursor[r - 1] : 0u;
-  end[r] = cursor[r];
+  const uint32_t s0 = start[r], s1 = start[r + 1];
+  uint32_t j = tile_start[r];
+  for (uint32_t st = s0; st < s1; st += 64u) tiles[j++] = make_uint4(st, min(64u, s1 - st), (uint32_t)r, 0u);
 }
 
 // Compiled per policy kind and with / without the day bitmaps + return snapshot (like k_rollout64): with two waves per

@@ -20,7 +20,8 @@ struct StepArgs {
   int64_t gid0;
   ResetCfg rc;
   int32_t act_dtype;
-  int32_t uni_t, uni_nd;  // k_step64 packed variant: the day and episode length shared by every env (lock step)
+  int32_t uni_nd;         // k_step64 packed variant: the episode length shared by every env (a table constant; the day
+                          // is read from the mirror's day word, StateArrays::pk_day)
   int32_t skip_finished;  // k_step64: envs whose episode is over are left untouched (reward 0, done 1, no status bit)
   int32_t next_step;      // AUTORESET variants: restart on the call after the terminal step (W2A_STEP_NEXT_STEP)
 };

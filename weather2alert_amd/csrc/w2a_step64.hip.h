@@ -336,6 +336,9 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   if (!REWARD_GIVEN) a.reward[e] = r;
   a.done[e] = done ? 1 : 0;
 #endif
+  // the tile's day word moves on with its envs (lock step: the same day and length in every lane; the terminal step
+  // leaves the day where it is, env.py:256-259)
+  if (PACKED && lane == 0) a.st.pk_day[wave_env0 >> 6] = t2;
   if (done && a.last_return) a.last_return[e] = ret;
   if (st_bits) atomicOr(a.status, (int)st_bits);
   }
@@ -372,12 +375,13 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   }
 }
 
-// packed variant: 8 + 8 B per env, the uniform day / episode length from the kernel arguments; the canonical words are
-// rebuilt in registers so that the tile code is shared
-__device__ __forceinline__ void s64_load_packed(const StepArgs &a, uint32_t e, u3 &h, u3 &c, int32_t &act) {
+// packed variant: 8 + 8 B per env, the uniform day from the tile's day word (device memory: a recorded step finds the right
+// day on every replay), the episode length from the kernel arguments; the canonical words are rebuilt in registers so
+// that the tile code is shared
+__device__ __forceinline__ void s64_load_packed(const StepArgs &a, uint32_t e, uint32_t day, u3 &h, u3 &c, int32_t &act) {
   const uint2 ph = a.st.pk_hot[e];
   const uint2 pc = a.st.pk_c[e];
-  h.a = pack_d0((uint32_t)a.uni_t, PK_USED(ph.x), PK_STREAK(ph.x), PK_HIST(ph.x) & 1u, 0u);
+  h.a = pack_d0(day, PK_USED(ph.x), PK_STREAK(ph.x), PK_HIST(ph.x) & 1u, 0u);
   h.b = pack_d1(PK_HIST(ph.x), (uint32_t)a.uni_nd, PK_FIN(ph.x));
   h.c = ph.y;
   c.a = pc.x & 0xFFFFu;
@@ -415,11 +419,22 @@ __global__ __launch_bounds__(BLOCK, FIXES ? 3 : W2A_S64_MIN_WAVES) void k_step64
   const uint32_t lb = logical_block(blockIdx.x, gridDim.x >> 3);  // grid is a multiple of 8 workgroups
   const int64_t wave_env0 = ((int64_t)lb * S64_WAVES + wave) * (S64_ENVS * W2A_S64_TILES);
   if (wave_env0 >= a.n) return;  // whole wave past the end (padding tiles); no workgroup barrier is used below
+  // packed variant: the day of this wave's tile(s), one word per 64 envs (wave-uniform address)
+  uint32_t dayn = 0;
+  if (PACKED) {
+    dayn = a.st.pk_day[wave_env0 >> 6];
+    // poisoned mirror: the host could not keep the packed form current for a recorded graph (w2a_bookkeeping.h,
+    // graph_packed) -- a replay must not step stale state: nothing is touched, the status word says why
+    if (dayn == W2A_PK_DAY_POISON) {
+      if (lane == 0) atomicOr(a.status, (int)W2A_ST_STALE_GRAPH);
+      return;
+    }
+  }
   u3 hn, cn;
   int32_t an;
   {
     const int64_t env = wave_env0 + lane;
-    if (PACKED) s64_load_packed(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
+    if (PACKED) s64_load_packed(a, (uint32_t)(env < a.n ? env : a.n - 1), dayn, hn, cn, an);
     else s64_load_state(a, (uint32_t)(env < a.n ? env : a.n - 1), hn, cn, an);
   }
   // slot -> observation column of the 4 row slots this lane owns in the row phase; requested together with the
@@ -437,8 +452,10 @@ __global__ __launch_bounds__(BLOCK, FIXES ? 3 : W2A_S64_MIN_WAVES) void k_step64
     const int32_t act = an;
     if (i + 1 < W2A_S64_TILES && env0 + S64_ENVS < a.n) {
       const int64_t en = env + S64_ENVS;
-      if (PACKED) s64_load_packed(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
-      else s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
+      if (PACKED) {
+        dayn = a.st.pk_day[(env0 + S64_ENVS) >> 6];
+        s64_load_packed(a, (uint32_t)(en < a.n ? en : a.n - 1), dayn == W2A_PK_DAY_POISON ? 0u : dayn, hn, cn, an);
+      } else s64_load_state(a, (uint32_t)(en < a.n ? en : a.n - 1), hn, cn, an);
     }
     s64_tile<WRITE_OBS, REWARD_GIVEN, PACKED, AUTORESET, FIXES>(a, sw, lane, env0, valid, e, h, c, act, so);
     // the per-wave LDS record is rewritten by the next tile
@@ -449,7 +466,8 @@ __global__ __launch_bounds__(BLOCK, FIXES ? 3 : W2A_S64_MIN_WAVES) void k_step64
 }
 
 // canonical -> lock-step mirror (entering the packed form: once per episode) and back (before anything else reads the
-// canonical arrays). t / n_days / finished are uniform and come from the host's bookkeeping.
+// canonical arrays). The day of a 64-env tile is that of its first env (lock step: the host packs only batches it knows
+// to be on one day); the episode length is a table constant the host passes.
 __global__ void k_pack_state(StateArrays st, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -457,19 +475,25 @@ __global__ void k_pack_state(StateArrays st, int64_t n) {
   const u3 c = st.stepc[i];
   st.pk_hot[i] = make_uint2(pk_pack_hot(D0_USED(h.a), D0_STREAK(h.a), D1_HIST(h.b), D1_FIN(h.b)), h.c);
   st.pk_c[i] = make_uint2((c.a & 0xFFFFu) | (W_COL(c.c) << 16), (c.b & 0x3FFFFFu) | (W_SAMPLE(c.c) << 22));
+  if ((i & 63) == 0) st.pk_day[i >> 6] = D0_T(h.a);
 }
-__global__ void k_unpack_state(StateArrays st, int64_t n, int32_t t, int32_t n_days) {
+__global__ void k_unpack_state(StateArrays st, int64_t n, int32_t n_days) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint2 ph = st.pk_hot[i];
+  const uint32_t t = st.pk_day[i >> 6];
   const uint32_t used = PK_USED(ph.x), hist = PK_HIST(ph.x), fin = PK_FIN(ph.x), last = hist & 1u;
   // at_budget as the last step left it (env.py:242: decided BEFORE that day's action); False after a reset
   const uint32_t atb = ((t > 0 || fin) && (int32_t)(used - last) == (int32_t)st.stepc[i].a) ? 1u : 0u;
   u3 h;
-  h.a = pack_d0((uint32_t)t, used, PK_STREAK(ph.x), last, atb);
+  h.a = pack_d0(t, used, PK_STREAK(ph.x), last, atb);
   h.b = pack_d1(hist, (uint32_t)n_days, fin);
   h.c = ph.y;
   st.hot3[i] = h;
+}
+__global__ void k_poison_mirror(StateArrays st, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ((n + 63) >> 6)) st.pk_day[i] = W2A_PK_DAY_POISON;
 }
 
 #endif  // W2A_STEP64_HIP_H

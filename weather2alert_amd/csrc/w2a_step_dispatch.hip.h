@@ -32,9 +32,10 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   dim3 grid(grid_for(env->n)), block(BLOCK);
   hipStream_t s = (hipStream_t)stream;
   // Stream capture (hipGraph): a captured step is replayed later without the host's bookkeeping being run again, so
-  // nothing that depends on it may be baked into the graph -- the packed variant takes the day as a kernel ARGUMENT.
-  // Under capture the canonical kernels run (they read the day from memory), and a handle that has ever been captured
-  // keeps to the canonical form for good (a replay advances days behind the host's back): w2a_bookkeeping.h, bk_step.
+  // nothing that depends on it may be baked into the graph: every step kernel reads the day from device memory (the
+  // packed variant from the mirror's per-tile day word), and no conversion between the two forms of the state is ever
+  // recorded -- the recorded kernel's form stays the handle's primary form from then on (w2a_bookkeeping.h: bk_step,
+  // graph_canon / graph_packed, bk_end_call).
   bool capturing = false;
   {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -47,10 +48,18 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // which kernel, on which form of the per-env state; the form conversions (k_pack_state / k_unpack_state) are launched
   // from inside, and the day every env is on after this call is recorded there
   HipDev dv{env, s};
+  const W2aBook before = env->bk;
   const BkStepPlan plan = bk_step(env->bk, dv, wide, autoreset, given, (flags & W2A_STEP_UNPACKED) != 0, capturing);
   if (plan.kernel < 0)
-    return fail(W2A_ERR_STATE, "w2a_step: stream capture started while the step state is in its packed lock-step form; "
-                               "call w2a_get_state (or any entry point that reads the canonical state) before capturing");
+    return fail(W2A_ERR_STATE, "w2a_step: this step runs on the canonical state words, which are not current (the state is "
+                               "in its packed lock-step form), and a conversion cannot be recorded into a hipGraph; call "
+                               "w2a_get_state before capturing -- or, on a handle with a recorded packed step, do not "
+                               "record a step of another kind");
+  // a launch that fails leaves the state as it was: the bookkeeping goes back too (a conversion that ran stays noted)
+#define W2A_STEP_TRY(expr) \
+  do { hipError_t _e = (expr); \
+       if (_e != hipSuccess) { bk_step_rollback(env->bk, before, plan); if (!capturing) bk_end_call(env->bk, dv); \
+                               return fail(W2A_ERR_HIP, #expr ": %s", hipGetErrorString(_e)); } } while (0)
   if (plan.kernel != W2A_BK_STEP_CLASSIC) {
     // the lean 64-envs-per-wave form (w2a_step64.hip.h); a workgroup covers BLOCK * W2A_S64_TILES envs, the grid is a
     // multiple of 8 workgroups
@@ -59,13 +68,14 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     dim3 grid64((unsigned)(((tiles + 7) / 8) * 8));
     if (plan.kernel == W2A_BK_STEP_PACKED) {
       // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
-      a.uni_t = plan.uni_t; a.uni_nd = plan.uni_nd;
+      a.uni_nd = plan.uni_nd;
       if (env->tb.fixes) {  // corrected-semantics flags: their own variants, the faithful kernels carry none of the code
         if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, false, true>), grid64, block, 0, s, a);
         else hipLaunchKernelGGL((k_step64<true, false, true, false, true>), grid64, block, 0, s, a);
       } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false, true>), grid64, block, 0, s, a);
-      HIP_TRY(hipGetLastError());
+      W2A_STEP_TRY(hipGetLastError());
+      bk_end_call(env->bk, dv);
       return W2A_OK;
     }
     if (given) {
@@ -86,7 +96,8 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
       if (no_obs) hipLaunchKernelGGL((k_step64<false, false>), grid64, block, 0, s, a);
       else hipLaunchKernelGGL((k_step64<true, false>), grid64, block, 0, s, a);
     }
-    HIP_TRY(hipGetLastError());
+    W2A_STEP_TRY(hipGetLastError());
+    if (!capturing) bk_end_call(env->bk, dv);
     return W2A_OK;
   }
 #define W2A_LAUNCH(AR, OB) \
@@ -95,7 +106,9 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   if (autoreset) { if (no_obs) W2A_LAUNCH(true, false); else W2A_LAUNCH(true, true); }
   else { if (no_obs) W2A_LAUNCH(false, false); else W2A_LAUNCH(false, true); }
 #undef W2A_LAUNCH
-  HIP_TRY(hipGetLastError());
+  W2A_STEP_TRY(hipGetLastError());
+#undef W2A_STEP_TRY
+  if (!capturing) bk_end_call(env->bk, dv);
   return W2A_OK;
 }
 

@@ -99,6 +99,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          pm_kernel, reward_path -- never what; each may also be passed by name (step_kernel="wide", ...).
                          Every combination gives the same results up to the order of the fp64 additions (~1e-7 for
                          the posterior-mean kernels); the defaults are the fastest choice on MI355X.
+    pm_sync_group        pm_kernel="auto" only: a torch.distributed process group (True = the default group) whose ranks
+                         must all use the kernel its first rank measured fastest -- the choice is then BROADCAST inside the
+                         first reset() (a collective: every rank of the group must get there). Default None: no
+                         communication, each process keeps its own choice; for one kernel on every rank without a
+                         collective pass pm_kernel=<name> (the default "matrix_i8" is such a name).
     tables               pre-compiled CompiledTables (skips file loading)
     env_gid0             global id of env 0 (multi-GPU sharding keeps results shard-invariant)
     """
@@ -129,6 +134,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         fixes: set | list | None = None,
         reward_mode: Literal["sampled", "posterior_mean"] = "sampled",
         kernel: KernelOptions | None = None,
+        pm_sync_group=None,
         **kernel_overrides,  # any field of KernelOptions by name (step_kernel=..., pm_kernel=..., write_obs=..., ...)
     ):
         # HOW things are computed (never what): one record, weather2alert_amd/options.py
@@ -179,6 +185,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self.pm_kernel = pm_kernel
         self.pm_kernel_choice = None if pm_kernel == "auto" else pm_kernel  # decided after the first reset
         self.pm_kernel_timing_us: dict = {}
+        self.pm_sync_group = pm_sync_group
         self.rollout_order = bool(rollout_order)  # rollout() visits the envs in feature-row order (speed only; A/B)
         # rollout(): the table-sourced part of the logits on the int8 matrix cores (needs the visiting order, a batch in
         # lock step and faithful semantics; speed only; A/B)
@@ -365,6 +372,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
                            "(reference: KeyError at env.py:127 / ValueError at env.py:121)")
         if bits & _ffi.ST_BAD_ACTION:
             raise ValueError("step: actions must be 0 or 1 (action_space = Discrete(2))")
+        if bits & _ffi.ST_STALE_GRAPH:
+            raise RuntimeError("a replayed hipGraph holds step() calls on the packed lock-step form of this env's state, "
+                               "which could not be kept current (a masked reset, injected budgets or a restored checkpoint "
+                               "since the capture): those replayed steps did nothing. Reset the whole batch (or capture "
+                               "again) before replaying (include/w2a.h, w2a_state_bytes)")
         return bits
 
     def state(self) -> dict[str, torch.Tensor]:
@@ -411,9 +423,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._state.copy_(sd["state"])
         self._state[:256].copy_(hdr)
         # the state buffer changed behind the library: it forgets what it derived and scans the restored buffer for its
-        # largest budget, sticky ones included (the one call that waits for the device)
+        # largest budget, sticky ones included (waits for this stream -- the one the copy above ran on -- and no other)
         with torch.cuda.device(self.device):
-            _ffi.check(self._lib.w2a_invalidate(self._h), "w2a_invalidate")
+            _ffi.check(self._lib.w2a_invalidate(self._h, self._stream()), "w2a_invalidate")
         self._obs.copy_(sd["obs"])
         self._final_return.copy_(sd["final_return"])
         self._reward.copy_(sd["reward"])
@@ -633,14 +645,18 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 best[name] = min(times[1:])
             self.pm_kernel_timing_us = best
             self.pm_kernel_choice = min(best, key=best.get)
-            # one decision per job: the kernels differ in the last bits, and the device RNG's shard invariance (env_gid0)
-            # would be worth little if the same global env id got other reward bits on another rank
-            import torch.distributed as td
+            # The kernels differ in the last bits, and the device RNG's shard invariance (env_gid0) would be worth little
+            # if the same global env id got other reward bits on another rank: with pm_sync_group= every rank of that
+            # group takes the group's first rank's choice. A COLLECTIVE -- so only when the caller asked for it (every
+            # rank of the group must then build such an env and reach its first reset()); without it "auto" is a
+            # per-process choice (say pm_kernel=<name> for a fixed one).
+            if self.pm_sync_group is not None:
+                import torch.distributed as td
 
-            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
                 names = list(_ffi.PM_KERNELS)
                 pick = torch.tensor([names.index(self.pm_kernel_choice)], dtype=torch.int32, device=self.device)
-                td.broadcast(pick, src=0)
+                group = None if self.pm_sync_group is True else self.pm_sync_group
+                td.broadcast(pick, src=td.get_global_rank(group, 0) if group is not None else 0, group=group)
                 self.pm_kernel_choice = names[int(pick.item())]
             _ffi.check(self._lib.w2a_set_posterior_kernel(self._h, _ffi.PM_KERNELS[self.pm_kernel_choice]),
                        "w2a_set_posterior_kernel")
@@ -748,7 +764,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
         with torch.cuda.device(dev):
             if not self._pm and getattr(self, "_order_stale", True) and self.rollout_order:
                 if self._order_ws is None:
+                    # attached from here on: every later whole-batch reset leaves the feature-row counts and per-env ranks
+                    # in it (the first pass of the counting sort, inside k_reset), w2a_rollout_order only scans and places
                     self._order_ws = torch.empty(self._lib.w2a_rollout_order_workspace_bytes(n, ct.S_w * ct.Y), dtype=torch.uint8, device=dev)
+                    _ffi.check(self._lib.w2a_rollout_order_attach(self._h, self._order_ws.data_ptr(), self._order_ws.numel()),
+                               "w2a_rollout_order_attach")
                 _ffi.check(self._lib.w2a_rollout_order(self._h, self._order_ws.data_ptr(), self._order_ws.numel(),
                                                        self._stream()), "w2a_rollout_order")
                 self._order_stale = False

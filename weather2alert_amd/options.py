@@ -27,7 +27,8 @@ class KernelOptions:
     # reward_mode="posterior_mean": which kernel computes the contraction -- "matrix_i8" (int8 matrix cores on exact
     # fixed-point digits; the default: fastest, and a fixed choice keeps rewards bit-reproducible across runs and ranks),
     # "vector" (fp64 FMAs with DPP-broadcast coefficients), "matrix" (fp64 matrix cores), "auto" (times the three on the
-    # env's own batch after the first reset and keeps the fastest; rank 0's choice for every rank of a job)
+    # env's own batch after the first reset and keeps the fastest -- a per-process choice unless the env is given
+    # pm_sync_group=, which broadcasts the group's first rank's choice: a collective inside the first reset())
     pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "matrix_i8"
 
     def __post_init__(self):
