@@ -76,6 +76,8 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the reported extras (always-alert policy, sorted episode order, posterior-mean reward)")
+    p.add_argument("--no-parity", action="store_true",
+                   help="skip the oracle replay of a strided sample of the timed batch that follows the timed region")
     p.add_argument("--no-calibration", action="store_true",
                    help="skip the in-process copy-rate / access-pattern probe that follows the timed region")
     p.add_argument("--seed", type=int, default=0)
@@ -92,10 +94,25 @@ def parse(argv=None):
                    help="--gpus N self-launcher: seconds after which still-running ranks are terminated")
     p.add_argument("--fail-rank", type=int, default=-1,
                    help="(launcher test hook) this rank exits with code 3 right after start-up")
+    p.add_argument("--sweep", default=None, metavar="N1,N2,...",
+                   help="scaling sweep in one command, e.g. --sweep 1,2,4,8: this process (which never touches a GPU) runs "
+                        "`bench.py --gpus N` for every N in turn, each as a fresh group of child processes, and prints ONE "
+                        "JSON line per N (value, per-GPU value, the job's own single-GPU reference, efficiency, what the "
+                        "collective costs, ranks seen) plus a closing summary line. Default workload: configs4 for every N, "
+                        "N = 1 included, so that all lines share one workload; --scaling weak (default) or strong")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the multi-rank path (ranks share the GPUs there are; with the "
                         "launcher_stub workload it needs no GPU at all)")
     a = p.parse_args(argv)
+    if a.sweep is not None:
+        try:
+            a.sweep = [int(x) for x in a.sweep.split(",") if x.strip()]
+        except ValueError:
+            p.error("--sweep takes a comma-separated list of GPU counts, e.g. 1,2,4,8")
+        if not a.sweep or min(a.sweep) < 1:
+            p.error("--sweep needs positive GPU counts")
+        if a.workload is None:
+            a.workload = "configs4"
     if a.workload is None:
         a.workload = "configs2" if a.gpus == 1 else "configs4"
     return a
@@ -176,6 +193,59 @@ def self_launch(args) -> int:
         return 0
     print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
     return 1
+
+
+def run_sweep(args) -> int:
+    """`--sweep N1,N2,...`: one `bench.py --gpus N` job per entry, one after another, each a fresh child (which launches
+    its own ranks for N > 1): nothing of one job -- process group, RCCL communicators, device memory -- survives into the
+    next. This process imports no torch and touches no GPU. One condensed JSON line per N as it finishes, then a summary
+    line with the efficiencies relative to the sweep's own N = 1 (or smallest-N) line."""
+    import subprocess
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "per_gpu_value",
+            "single_gpu_value", "weak_efficiency", "efficiency_vs_rank0_alone", "no_collective_value",
+            "collective_overhead_frac", "collective_ms", "rccl_ranks_seen", "status_bits", "mean_final_return")
+    lines, rc_all = [], 0
+    for n in args.sweep:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--workload", args.workload, "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--scaling", args.scaling, "--backend", args.backend, "--seed", str(args.seed),
+               "--launch-timeout", str(args.launch_timeout), "--no-extras", "--no-cpu-baseline"]
+        if args.num_envs:
+            cmd += ["--num-envs", str(args.num_envs)]
+        if args.no_obs:
+            cmd.append("--no-obs")
+        if args.no_parity:
+            cmd.append("--no-parity")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.launch_timeout + 120)
+            out, err, rc = r.stdout, r.stderr, r.returncode
+        except subprocess.TimeoutExpired as e:
+            out, err, rc = (e.stdout or ""), (e.stderr or ""), 124
+            out, err = (out.decode() if isinstance(out, bytes) else out), (err.decode() if isinstance(err, bytes) else err)
+        js = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if rc != 0 or not js:
+            rc_all = rc or 1
+            line = {"sweep_n": n, "error": f"bench.py --gpus {n} exited with code {rc}", "stderr_tail": err[-1500:]}
+        else:
+            d = json.loads(js[-1])
+            line = {"sweep_n": n, **{k: d.get(k) for k in keep}, "workload": (d.get("config") or {}).get("workload"),
+                    "num_envs_per_gpu": (d.get("config") or {}).get("num_envs_per_gpu"),
+                    "parity_ok": (d.get("parity") or {}).get("ok"), "job_wall_s": round(time.time() - t0, 1)}
+        lines.append(line)
+        print(json.dumps(line), flush=True)
+    good = [ln for ln in lines if "error" not in ln]
+    summary = {"sweep": args.sweep, "scaling": args.scaling, "workload": args.workload, "failed": [ln["sweep_n"] for ln in lines if "error" in ln]}
+    if good:
+        base = min(good, key=lambda ln: ln["sweep_n"])
+        # weak: per-GPU work fixed -> ideal value grows with N; strong: total work fixed -> ideal value grows with N too
+        # (the same envs finish N times faster). Either way: value / (value at the smallest N x N / that N)
+        summary["efficiency_vs_smallest_n"] = {
+            str(ln["sweep_n"]): ln["value"] / (base["value"] * ln["sweep_n"] / base["sweep_n"]) for ln in good}
+        summary["baseline_n"] = base["sweep_n"]
+    print(json.dumps(summary), flush=True)
+    return rc_all
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -443,6 +513,124 @@ def box_calibration(env, dt, ct, packed, torch):
     return out
 
 
+# ------------------------------------------------------------------------------------------ parity of the timed batch
+def parity_check(env, sd, ct, pool, act_log, torch, extra_steps=8, max_sample=4096):
+    """Does the batch that was just TIMED hold what the reference would hold? (cpu-baseline leg: the oracle is the checker,
+    outside the timed region.) For a strided sample of envs (env 0 and the last one included):
+      * the episode tuples the device RNG drew for the current episode -- and the budget stickiness chain from episode 0 --
+        against the NumPy restatement of the draw (oracle/sequence_model.draw_episodes);
+      * the last FINISHED episode replayed day by day on the float64 VectorOracle from the recorded action tensors
+        (act_log: which of the 16 pool tensors every step used): its return against the env's final_return;
+      * the current episode replayed up to today: integer state bit-exact, the observation rows the env holds bit-exact,
+        the running return, and the reward of the last timed step;
+      * `extra_steps` further steps of env and oracle side by side: every reward, observation row and done flag.
+    Returns the `parity` object of the JSON line."""
+    import numpy as np
+
+    from oracle import heatalert_oracle as O
+    from oracle import sequence_model as SM
+
+    n, T = env.num_envs, ct.T
+    idx = np.unique(np.concatenate([np.arange(0, n, max(n // max_sample, 1)), [n - 1]]))
+    it = torch.as_tensor(idx, device=env.device)
+    out = {"sampled": int(len(idx)), "reward_tol": 1e-5, "extra_checked_steps": extra_steps}
+    st = {k: v[it].cpu().numpy() for k, v in env.state().items()}
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    pool_np = [p[it].cpu().numpy().astype(np.int64) for p in pool]
+    ints_ok, notes = True, []
+
+    def same(name, got, want):
+        nonlocal ints_ok
+        if not np.array_equal(np.asarray(got), np.asarray(want)):
+            ints_ok = False
+            notes.append(f"{name} differs for {int((np.asarray(got) != np.asarray(want)).sum())} sampled envs")
+
+    e_cur = st["episode_no"]
+    lock = len(np.unique(e_cur)) == 1 and len(np.unique(st["t"])) == 1 and not st["finished"].any()
+    if not lock or env.seed_mode != "device" or env._reset_cfg is None:
+        return {**out, "skipped": "the batch is not in lock step on device-RNG episodes: no common history to replay"}
+    e_cur, t_cur = int(e_cur[0]), int(st["t"][0])
+    # ---- episode tuples: the restated device RNG, with the sticky-budget chain from episode 0 (env.py:167-170, Q9)
+    tuples = {}
+    if env.episode_order == "iid":
+        sticky = np.full(len(idx), -1, np.int64)
+        for ep in range(e_cur + 1):
+            cw, yi, cc, sm, b, sticky = SM.draw_episodes(ct, env._reset_cfg, env.env_gid0 + idx, np.full(len(idx), ep), sticky,
+                                                         "augment" in env.fixes)
+            if ep >= e_cur - 1:
+                tuples[ep] = (cw, yi, cc, sm, b)
+        for name, want in zip(("county_w", "year_i", "coef_col", "sample", "budget"), tuples[e_cur]):
+            same(f"episode tuple ({name})", st[name], want)
+        out["tuples"] = "restated device RNG, sticky-budget chain from episode 0"
+    else:  # episode_order='sorted' relabels envs after every reset: the tuples are taken from the state itself
+        tuples[e_cur] = tuple(st[k].astype(np.int64) for k in ("county_w", "year_i", "coef_col", "sample", "budget"))
+        out["tuples"] = "read back from the env (sorted order relabels env indices)"
+    n_logged = len(act_log)
+    worst_r, worst_ret, steps_replayed, episodes = 0.0, 0.0, 0, []
+    # ---- the last finished episode: its return
+    last_r = None
+    if e_cur - 1 in tuples and n_logged >= t_cur + T:
+        V.reset(*tuples[e_cur - 1])
+        ret = np.zeros(len(idx))
+        for k in range(T):
+            _, r, done, _ = V.step(pool_np[act_log[n_logged - t_cur - T + k]])
+            ret += r
+            last_r = r
+        assert done.all()
+        fr = env._final_return[it].cpu().numpy().astype(np.float64)
+        err = np.abs(fr - ret)
+        worst_ret = float(np.max(err / (2e-6 * np.abs(ret) + 2e-5)))  # in units of the suite's return tolerance
+        out["final_return_max_abs_err"] = float(err.max())
+        steps_replayed += T
+        episodes.append(e_cur - 1)
+    # ---- the current episode up to today
+    obs_o = V.reset(*tuples[e_cur])
+    ret = np.zeros(len(idx))
+    for k in range(t_cur):
+        obs_o, r, done, _ = V.step(pool_np[act_log[n_logged - t_cur + k]])
+        ret += r
+        last_r = r
+    steps_replayed += t_cur
+    episodes.append(e_cur)
+    same("t", st["t"], V.t); same("used", st["used"], V.used); same("streak", st["streak"], V.streak)
+    same("remaining budget", st["budget"] - st["used"], V.budget - V.used)
+    same("last_actual", st["last_actual"], V.last_actual)
+    hist14 = np.zeros(len(idx), np.int64)
+    for k in range(14):
+        hist14 |= V.hist[:, 13 - k].astype(np.int64) << k
+    same("14-day history", st["hist14"], hist14)
+    obs_ok = None
+    if env.write_obs:
+        obs_ok = bool(np.array_equal(env._obs[it].cpu().numpy(), obs_o.astype(np.float32)))
+    err = np.abs(st["episode_return"].astype(np.float64) - ret)
+    out["episode_return_max_abs_err"] = float(err.max())
+    worst_ret = max(worst_ret, float(np.max(err / (2e-6 * np.abs(ret) + 2e-5))))
+    if last_r is not None:  # the reward buffer still holds the last timed step's rewards
+        worst_r = float(np.abs(env._reward[it].cpu().numpy().astype(np.float64) - last_r).max())
+    # ---- a few more steps side by side: every reward, row and flag
+    done_ok = True
+    for k in range(extra_steps):
+        if t_cur + k >= T - 1:
+            break  # not across the terminal step: the env's own autoreset would follow
+        a = pool[k & 15]
+        obs, r, done, _, _ = env.step(a)
+        obs_o, r_o, done_o, _ = V.step(pool_np[k & 15])
+        worst_r = max(worst_r, float(np.abs(r[it].cpu().numpy().astype(np.float64) - r_o).max()))
+        done_ok = done_ok and bool(np.array_equal(done[it].cpu().numpy(), done_o))
+        if env.write_obs:
+            obs_ok = obs_ok and bool(np.array_equal(obs[it].cpu().numpy(), obs_o.astype(np.float32)))
+        steps_replayed += 1
+    if not done_ok:
+        ints_ok = False
+        notes.append("done flags differ")
+    out.update(episodes_replayed=episodes, env_steps_replayed_per_env=steps_replayed, max_abs_reward_err=worst_r,
+               return_err_over_tolerance=worst_ret, ints_exact=bool(ints_ok), obs_exact=obs_ok,
+               status_bits=env.check_status(),
+               ok=bool(ints_ok and worst_r <= 1e-5 and worst_ret <= 1.0 and obs_ok is not False), notes=notes,
+               checker="oracle/heatalert_oracle.VectorOracle (float64) + oracle/sequence_model.draw_episodes, after the timed region")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def timed_steps(env, pool, steps, torch):
     """(device ms, wall s) of `steps` back-to-back step() calls (no autoreset boundary inside)."""
@@ -457,7 +645,7 @@ def timed_steps(env, pool, steps, torch):
     return e0.elapsed_time(e1), time.perf_counter() - t0
 
 
-def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T):
+def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T, wname_main=None):
     """Reported extras of the single-GPU run, each measured in the same process after the headline; a failure in one of
     them is recorded under its key and never loses the headline JSON line."""
 
@@ -615,12 +803,75 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
                     "N x this one, not with the configs[2] headline above"}
         e5.close()
 
+    def configs1():
+        # BASELINE configs[1] in the driver's own line: 65 536 envs, weights/linear, random county per env. Below 131 072
+        # envs w2a_step picks the 4-lanes-per-env kernel (k_step, canonical 161-B state: more, shorter waves hide the two
+        # dependent memory hops better); at 5 us per launch the host's launch rate matters, so the same steps are also
+        # timed as a hipGraph of G recorded steps (in-kernel autoreset, so that every replay is the same work)
+        w1, n1, aug1, desc1 = WORKLOADS["configs1"]
+        if wname_main == w1:
+            dt1, ct1 = dt, ct
+        else:
+            sd1 = synth.make_synth(w1, years=list(range(2006, 2017)), n_samples=100, seed=args.seed, extra_confounder_fips=60)
+            ct1 = tables.compile_from_synth(sd1)
+            dt1 = tables.DeviceTables(ct1, device)
+        g1 = torch.Generator(device=device).manual_seed(4321)
+        pool1 = [(torch.rand(n1, device=device, generator=g1) < 0.1).to(torch.int32) for _ in range(16)]
+        e1 = HeatAlertVecEnv(n1, tables=dt1, device=device, similar_climate_counties=aug1, write_obs=not args.no_obs)
+        e1.reset(seed=args.seed)
+        timed_steps(e1, pool1, 20, torch)
+        kms, kwall = timed_steps(e1, pool1, 120, torch)
+        us = kms * 1e3 / 120
+        cb1 = compulsory_bytes(ct1.n_obs, not args.no_obs, e1.packed_state)
+        res = {"workload": desc1, "step_kernel": e1.last_step_kernel, "kernel_us": us, "value": n1 * 120 / kwall,
+               "unit": "env-steps/s (eager step() loop, wall clock)", "kernel_env_steps_per_s": n1 / us * 1e6,
+               "compulsory_bytes_per_env_step": cb1["total"],
+               "roofline_frac": cb1["total"] * n1 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "note": "kernel_us = HIP events around 120 back-to-back step() calls of one episode / 120: at this size it "
+                       "contains the launch gaps the host leaves (the kernel alone: profiles/, rocprofv3 --kernel-trace)"}
+        e1.close()
+        # the same steps as one hipGraph per G = 51 days (three replays = one 153-day episode)
+        G, reps = 51, 30
+        e2 = HeatAlertVecEnv(n1, tables=dt1, device=device, similar_climate_counties=aug1, write_obs=not args.no_obs,
+                             lockstep=False)
+        e2.reset(seed=args.seed)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            e2.step(pool1[0])
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(G):
+                e2.step(pool1[i & 15])
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(reps):
+            graph.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        gus = ev0.elapsed_time(ev1) * 1e3 / (reps * G)
+        cb2 = compulsory_bytes(ct1.n_obs, not args.no_obs, False)
+        res["hipgraph"] = {"steps_per_graph": G, "replays": reps, "us_per_step": gus, "value": n1 * G * reps / wall,
+                           "unit": "env-steps/s (wall clock)", "step_kernel": e2.last_step_kernel + " (in-kernel autoreset)",
+                           "roofline_frac": cb2["total"] * n1 / (gus * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "status_bits": e2.check_status()}
+        e2.close()
+        out["configs1_single_gpu"] = res
+
     guarded("always_alert_policy", always_alert)
     guarded("sorted_episode_order", sorted_order)
     guarded("posterior_mean_reward", posterior_mean)
     guarded("on_device_rollout", rollout)
     if args.workload == "configs2":
         guarded("configs4_single_gpu", configs4)
+    if args.workload != "configs1":
+        guarded("configs1_single_gpu", configs1)
 
 
 def main():
@@ -628,6 +879,8 @@ def main():
         print(json.dumps(_cpu_worker(tuple(json.loads(sys.argv[2])))))
         return 0
     args = parse()
+    if args.sweep:
+        return run_sweep(args)  # never imports torch, never touches a GPU
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # before anything imports torch / initialises a GPU
     rank = int(os.environ.get("RANK", "0"))
@@ -697,6 +950,7 @@ def main():
     seg_events = []  # (start, end) HIP events around the step launches of each episode inside the timed region
     seg_on = False
     packed_seen = []
+    act_log = []  # which of the 16 action tensors every step() of this env used, in order (the parity replay reads it)
 
     def one_step():
         nonlocal stepno
@@ -706,6 +960,7 @@ def main():
             ev.record()
             seg_events.append([ev, None])
         env.step(pool[stepno & 15])
+        act_log.append(stepno & 15)
         if seg_on and phase == 1:
             packed_seen.append(env.packed_state)  # host-side bookkeeping only: no device work, no sync
         if seg_on and env._host_auto and phase == T - 2 and seg_events and seg_events[-1][1] is None:
@@ -738,6 +993,7 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             env.step(pool[0])
+        act_log.append(0)
         torch.cuda.current_stream().wait_stream(side)
         with torch.cuda.graph(graph):
             for i in range(args.graph):
@@ -769,6 +1025,7 @@ def main():
         else:
             for _ in range(args.steps // args.graph):
                 graph.replay()
+                act_log.extend(i & 15 for i in range(args.graph))
                 before = stepno
                 stepno += args.graph
                 if stepno // T != before // T:
@@ -800,6 +1057,7 @@ def main():
         # again, untimed
         env.reset(seed=args.seed + 1)
         stepno = 0
+        act_log.clear()
         for _ in range(args.warmup):
             one_step()
         gather.wait()
@@ -820,11 +1078,6 @@ def main():
         use_gather = True
     status = env.check_status()
     mean_ret = float(gather.mean(env._final_return).item())
-    # This box's memory side, in this process, on this run's tables and CURRENT episode tuples: right AFTER the timed
-    # region. (Before it, the probe's ~50 ms of full-bandwidth work changed what a short window measures: the driver's
-    # 20 steps read 42.7 us per launch behind the probe against 35 us without it, profiles/r04/bench_driver_args_*.log
-    # -- the chip throttles for some milliseconds after a burst.)
-    calib = None if args.no_calibration else box_calibration(env, dt, ct, packed, torch)
     collective_ms = min(a.elapsed_time(b) for a, b in coll_ev) if coll_ev else None
 
     # step-kernel launch time, live: HIP events on the launch stream around back-to-back launches inside one
@@ -849,8 +1102,22 @@ def main():
         if env._host_auto and T - env._steps_in_episode <= k_steps:
             for _ in range(T - env._steps_in_episode):
                 env.step(pool[0])  # finish this episode: the measurement must not contain a reset kernel
+                act_log.append(0)
         kms, _ = timed_steps(env, pool, k_steps, torch)
+        act_log.extend(i & 15 for i in range(k_steps))
         kernel_us = kms * 1e3 / k_steps
+    # This box's memory side, in this process, on this run's tables and CURRENT episode tuples: AFTER every timing of the
+    # step kernel (the probe is ~50 ms of full-bandwidth work, and the chip throttles for some milliseconds after such a
+    # burst: in front of the driver's 20-step window it read 42.7 us per launch against 35 us without,
+    # profiles/r04/bench_driver_args_*.log -- and in front of the fallback timing above it would do the same)
+    calib = None if args.no_calibration else box_calibration(env, dt, ct, packed, torch)
+    # parity of the very batch that was timed, against the oracle (rank 0; cpu-baseline leg, outside every timed region)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            parity = parity_check(env, sd, ct, pool, act_log, torch)
+        except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
+            parity = {"error": repr(e), "ok": False}
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
@@ -952,10 +1219,11 @@ def main():
             "rccl_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "collective_ms": collective_ms,
             "status_bits": status, "mean_final_return": mean_ret, "setup_s": t_setup,
+            "parity": parity,
         }
         if world == 1 and args.episode_order == "iid" and not args.graph and not args.no_extras:
             env.close()
-            extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T)
+            extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T, wname)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd, ct, args.seed)

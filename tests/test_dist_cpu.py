@@ -155,6 +155,40 @@ def test_bench_launcher_eight_ranks_and_a_rank_that_dies_at_startup():
     assert slow.returncode == 124 and "launch-timeout" in slow.stderr
 
 
+@pytest.mark.timeout(240)
+def test_bench_sweep_runs_every_gpu_count_as_its_own_job():
+    """`bench.py --sweep 1,2,4 [--scaling ...]`: the parent never touches a GPU and runs one `--gpus N` job per entry as a
+    fresh child group, one JSON line per N + a summary line; a failing N is reported in its line and in the exit code
+    without losing the others. Rehearsed on gloo with the stub workload (the one command for the day
+    an 8-GPU node exists)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--backend", "gloo", "--workload", "launcher_stub", "--steps", "306",
+            "--warmup", "0", "--num-envs", "1024"]
+    r = subprocess.run(base + ["--sweep", "1,2,4"], capture_output=True, text=True, env=env, timeout=200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert [ln.get("sweep_n") for ln in lines[:-1]] == [1, 2, 4] and lines[-1]["sweep"] == [1, 2, 4]
+    for ln in lines[:-1]:
+        assert ln["n_gpus"] == ln["rccl_ranks_seen"] == ln["sweep_n"] and ln["num_envs_per_gpu"] == 1024 and ln["value"] > 0
+        if ln["sweep_n"] > 1:  # a multi-rank job judges itself; the sweep adds the cross-job figure
+            assert ln["single_gpu_value"] > 0 and ln["weak_efficiency"] > 0 and ln["collective_overhead_frac"] is not None
+    assert set(lines[-1]["efficiency_vs_smallest_n"]) == {"1", "2", "4"} and lines[-1]["efficiency_vs_smallest_n"]["1"] == 1.0
+    assert lines[-1]["failed"] == [] and lines[-1]["baseline_n"] == 1
+    # strong scaling: a fixed total split over the ranks; a total that does not divide is that job's error, not the sweep's end
+    st = subprocess.run(base[:-2] + ["--num-envs", "1026", "--scaling", "strong", "--sweep", "2,4"], capture_output=True, text=True,
+                        env=env, timeout=200)
+    sl = [json.loads(ln) for ln in st.stdout.splitlines() if ln.startswith("{")]
+    assert st.returncode != 0 and sl[0]["num_envs_per_gpu"] == 513 and sl[0]["scaling"] == "strong"
+    assert "error" in sl[1] and "divisible" in sl[1]["stderr_tail"] and sl[-1]["failed"] == [4]
+    bad = subprocess.run(base + ["--sweep", "1,x"], capture_output=True, text=True, env=env, timeout=60)
+    assert bad.returncode != 0 and "--sweep" in bad.stderr
+
+
 def test_bench_defaults_follow_baseline_configs():
     import importlib.util
 
@@ -163,6 +197,7 @@ def test_bench_defaults_follow_baseline_configs():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert b.parse([]).workload == "configs2" and b.parse(["--gpus", "8"]).workload == "configs4"
+    assert b.parse(["--sweep", "1,2,4,8"]).workload == "configs4" and b.parse(["--sweep", "1,8"]).sweep == [1, 8]
     assert b.WORKLOADS["configs4"][:3] == ("nn_full_medicare_all", 1048576, False)
     cb = b.compulsory_bytes(29, True)
     assert cb["total"] == 161 and b.compulsory_bytes(29, False)["total"] == 45
