@@ -189,7 +189,8 @@ int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augm
                          int sample_budget_mode, int sticky, int restart_episodes, const uint8_t *mask, float *obs,
                          void *stream);
 
-/* Parameters the same-step autoreset of w2a_step uses (same meaning as above). */
+/* Parameters the same-step autoreset of w2a_step uses (same meaning as above). They travel to the step kernels as
+ * arguments: a w2a_step recorded into a hipGraph keeps the parameters it was recorded with. */
 int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
                       int sample_budget_mode, int sticky);
 

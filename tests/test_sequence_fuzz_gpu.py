@@ -1,7 +1,8 @@
 """Model-based call-sequence fuzz of the libw2a handle: 1000 random sequences of 30-80 operations each
 -- resets (device RNG / injected tuples, masked / unmasked), steps in every kernel form and autoreset mode, partial and
 whole rollouts, state(), checkpoints, w2a_invalidate / w2a_set_budget_bound, episode_order="sorted", the posterior-mean
-reward with each kernel, hipGraph capture + replays -- mirrored on oracle/sequence_model.HandleModel; outputs compared
+reward with each kernel, hipGraph captures (of canonical and of packed steps) with replays right away and later in the
+sequence -- mirrored on oracle/sequence_model.HandleModel; outputs compared
 after every operation, w2a_query against what the sequence implies (tools/sequence_fuzz.py is the long form).
 The reference allows reset/step to interleave arbitrarily (env.py:133-184,238-262); round 3 added seven validity flags
 to the handle whose interleavings had one scripted test."""
@@ -42,6 +43,9 @@ def test_call_sequence_fuzz_against_the_model():
     assert tot["rollouts"] > 4 * N_SEQUENCES and tot["packed_steps"] > N_SEQUENCES // 2 and tot["mfma_rollouts"] > N_SEQUENCES // 4
     assert tot["graphs"] > N_SEQUENCES // 4 and tot["ckpt"] > N_SEQUENCES and tot["after_done"] > 5 * N_SEQUENCES
     assert tot["autoresets"] > 100 * N_SEQUENCES
+    # round 5: recorded graphs are replayed again later in the sequence, after whatever else happened to the handle; some
+    # of them hold PACKED steps, and some replays find their mirror poisoned (and must then do nothing but say so)
+    assert tot["replays"] > N_SEQUENCES and tot["packed_graphs"] >= 5 and tot["stale_replays"] >= 3, tot
 
 
 def test_policy_loop_over_a_ragged_batch_raises_no_status_bit():

@@ -212,6 +212,19 @@ __global__ __launch_bounds__(256) void k_copy16(const v4f *__restrict__ src, v4f
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
+// every device / host allocation of an entry point is registered here and released on EVERY way out (a failing second
+// hipMalloc used to leak the first GiB into the process that goes on to run the bench's extras)
+struct Scratch {
+  void *dev[16]; int nd = 0; void *host[4]; int nh = 0; hipEvent_t ev[2]; int ne = 0;
+  ~Scratch() {
+    for (int i = 0; i < ne; ++i) (void)hipEventDestroy(ev[i]);
+    for (int i = 0; i < nd; ++i) (void)hipFree(dev[i]);
+    for (int i = 0; i < nh; ++i) free(host[i]);
+  }
+  template <class T> hipError_t alloc(T **p, size_t bytes) { hipError_t e = hipMalloc((void **)p, bytes); if (e == hipSuccess) dev[nd++] = *p; return e; }
+  template <class T> T *halloc(size_t bytes) { T *p = (T *)malloc(bytes); if (p) host[nh++] = p; return p; }
+  hipError_t event(hipEvent_t *e) { hipError_t r = hipEventCreate(e); if (r == hipSuccess) ev[ne++] = *e; return r; }
+};
 #define TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_perr, sizeof g_perr, "%s: %s", #x, hipGetErrorString(e_)); return -3; } } while (0)
 static char g_perr[256] = "";
 extern "C" const char *w2a_probe_last_error(void) { return g_perr; }
@@ -221,10 +234,11 @@ extern "C" const char *w2a_probe_last_error(void) { return g_perr; }
 extern "C" int w2a_probe_copy(size_t bytes, int reps, float *gbs_out, void *stream) {
   if (!gbs_out || bytes < (1u << 20) || reps <= 0) { snprintf(g_perr, sizeof g_perr, "w2a_probe_copy: bad argument"); return -1; }
   hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
   v4f *a = nullptr, *b = nullptr;
-  TRY(hipMalloc(&a, bytes)); TRY(hipMalloc(&b, bytes));
+  TRY(sc.alloc(&a, bytes)); TRY(sc.alloc(&b, bytes));
   TRY(hipMemsetAsync(a, 0x3c, bytes, s));
-  hipEvent_t e0, e1; TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+  hipEvent_t e0, e1; TRY(sc.event(&e0)); TRY(sc.event(&e1));
   gbs_out[0] = 0.0f;
   for (int variant = 0; variant < 2; ++variant) {
     float best = 1e30f;
@@ -239,7 +253,7 @@ extern "C" int w2a_probe_copy(size_t bytes, int reps, float *gbs_out, void *stre
     gbs_out[1 + variant] = (float)(2.0 * (double)bytes / (best * 1e-3) / 1e9);
     if (gbs_out[1 + variant] > gbs_out[0]) gbs_out[0] = gbs_out[1 + variant];
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+  TRY(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -254,21 +268,22 @@ extern "C" int w2a_probe_step_pattern(const void *X, uint32_t rows_per_day, int3
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
   u3 *hot = nullptr, *stepc = nullptr; int32_t *act = nullptr; float *reward = nullptr, *obs = nullptr; uint8_t *done = nullptr;
-  TRY(hipMalloc(&hot, n * sizeof(u3))); TRY(hipMalloc(&stepc, n * sizeof(u3))); TRY(hipMalloc(&act, n * 4));
-  TRY(hipMalloc(&reward, n * 4)); TRY(hipMalloc(&done, n)); TRY(hipMalloc(&obs, n * 29 * 4));
+  TRY(sc.alloc(&hot, n * sizeof(u3))); TRY(sc.alloc(&stepc, n * sizeof(u3))); TRY(sc.alloc(&act, n * 4));
+  TRY(sc.alloc(&reward, n * 4)); TRY(sc.alloc(&done, n)); TRY(sc.alloc(&obs, n * 29 * 4));
   TRY(hipMemsetAsync(hot, 0, n * sizeof(u3), s)); TRY(hipMemsetAsync(act, 0, n * 4, s));
   TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rows_per_day), &rows_per_day, sizeof(rows_per_day), 0, hipMemcpyHostToDevice, s));
   {  // stepc.b / .c carry the gather indices (PROBE_DEP: they reach the gathers through the streamed state, like the env's)
-    u3 *hs = (u3 *)malloc(n * sizeof(u3));
-    uint32_t *hx = (uint32_t *)malloc(n * 4), *hw = (uint32_t *)malloc(n * 4);
+    u3 *hs = sc.halloc<u3>(n * sizeof(u3));
+    uint32_t *hx = sc.halloc<uint32_t>(n * 4), *hw = sc.halloc<uint32_t>(n * 4);
+    if (!hs || !hx || !hw) { snprintf(g_perr, sizeof g_perr, "w2a_probe_step_pattern: out of host memory"); return -2; }
     TRY(hipMemcpyAsync(hx, xrow, n * 4, hipMemcpyDeviceToHost, s)); TRY(hipMemcpyAsync(hw, wrow, n * 4, hipMemcpyDeviceToHost, s));
     TRY(hipStreamSynchronize(s));
     for (int64_t i = 0; i < n; ++i) { hs[i] = u3{}; hs[i].b = hx[i]; hs[i].c = hw[i]; }
     TRY(hipMemcpyAsync(stepc, hs, n * sizeof(u3), hipMemcpyHostToDevice, s)); TRY(hipStreamSynchronize(s));
-    free(hs); free(hx); free(hw);
   }
-  hipEvent_t e0, e1; TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+  hipEvent_t e0, e1; TRY(sc.event(&e0)); TRY(sc.event(&e1));
   const dim3 grid((unsigned)(n / 256)), block(256);
   const float4 *Xp = (const float4 *)X, *Wp = (const float4 *)W;
   for (int k = 0; k < 3; ++k) {
@@ -288,8 +303,7 @@ extern "C" int w2a_probe_step_pattern(const void *X, uint32_t rows_per_day, int3
     us_out[k] = best * 1e3f / (float)iters;
   }
   TRY(hipGetLastError());
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(hot); (void)hipFree(stepc); (void)hipFree(act); (void)hipFree(reward); (void)hipFree(done); (void)hipFree(obs);
+  TRY(hipStreamSynchronize(s));
   return 0;
 }
 #else

@@ -420,7 +420,7 @@ class Runner:
         K, R = int(rng.integers(1, 5)), int(rng.integers(1, 4))
         acts = [(rng.random(n) < 0.3).astype(np.int64) for _ in range(K)]
         at = [torch.as_tensor(a, device=self.dev).to(torch.int32) for a in acts]
-        if rng.random() < 0.5 and not m.pending_reset:
+        if (rng.random() < 0.5 or (m._can_pack() and m._wide())) and not m.pending_reset:
             self.op_step()  # a batch that can be packed enters the packed form here: the capture then records packed steps
             self.after_op()
         self.log.append(f"hipGraph: capture {K} steps, replay {R} times")
@@ -435,7 +435,8 @@ class Runner:
         if min(kinds) < 0 or len(set(kinds)) != 1:
             self.fail(f"{where}: the model expects the capture to be refused / to mix kernels: {kinds}")
         self.log[-1] += f" (recorded kernel {kinds[0]})"
-        self.graph = dict(g=g, acts=acts, at=at, kind=kinds[0], mode=m._mode(), step_kernel=m.step_kernel, write_obs=m.write_obs)
+        self.graph = dict(g=g, acts=acts, at=at, kind=kinds[0], mode=m._mode(), step_kernel=m.step_kernel, write_obs=m.write_obs,
+                          reset_cfg=m.reset_cfg)
         self.check_flags(where + " [after capture]")
         self.stats["graphs"] += 1
         self.stats["packed_graphs"] += kinds[0] == 2
@@ -475,8 +476,10 @@ class Runner:
 
     def replay_possible(self) -> bool:
         G, m = self.graph, self.m
+        # a recorded call keeps its ARGUMENTS: the step flags of the mode it was recorded in and -- with the in-kernel
+        # autoreset -- the w2a_set_autoreset parameters of that moment (include/w2a.h); the model replays with today's
         return (G is not None and not m.pending_reset and m._mode() == G["mode"] and m.step_kernel == G["step_kernel"]
-                and m.write_obs == G["write_obs"])
+                and m.write_obs == G["write_obs"] and (G["mode"] == "none" or m.reset_cfg == G["reset_cfg"]))
 
     # ------------------------------------------------------------------ sequence
     def run(self):
