@@ -92,7 +92,7 @@ def test_restored_sticky_budget_above_16_bits_never_reaches_the_packed_state():
     env.reset(seed=1, options={"budget": 65721})  # sticky from here on (Q9)
     env.step(torch.ones(n, dtype=torch.int32, device=dev))
     env.state()
-    _ffi.check(env._lib.w2a_invalidate(env._h), "w2a_invalidate")  # as after a restore; nothing stated afterwards
+    _ffi.check(env._lib.w2a_invalidate(env._h, env._stream()), "w2a_invalidate")  # as after a restore; nothing stated afterwards
     assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 0  # the library found 65 721 in the buffer by itself
     rng = np.random.default_rng(0)
     county = rng.integers(0, ct.S, n)

@@ -96,7 +96,16 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
     const size_t day = (size_t)(n_raw >> 40);
     const uint32_t li = c.b * PT_DRAWS + smp, wi = (c.b / PT_Y) * PT_DRAWS + smp;
     const bool need = ((c.c * 2654435761u) >> 24) < 13u;  // ~5 % of the envs alert today with an open gate
-#if PROBE_TABLE == 1
+#if PROBE_TABLE == 3
+    // ONE 16-B entry per env and head: {table part of the logit, the three run-time coefficients} from a day slice
+    // [day][feature row][draw] of 16-B entries (12.7 MB per day and head at 7 920 rows x 100 draws); no other gather
+    const float4 l = reinterpret_cast<const float4 *>(g_L)[day * rows * PT_DRAWS + li];
+    acc += l.x + l.y * 0.5f + l.z * 0.25f + l.w * 0.125f;
+    if (need) {
+      const float4 e = reinterpret_cast<const float4 *>(g_L)[((size_t)153 + day) * rows * PT_DRAWS + li];
+      acc += e.x + e.y * 0.5f + e.z * 0.25f + e.w * 0.125f;
+    }
+#elif PROBE_TABLE == 1
     const float2 l = reinterpret_cast<const float2 *>(g_L)[day * rows * PT_DRAWS + li];
     acc += l.x + (need ? l.y : 0.f);
 #else
@@ -105,10 +114,14 @@ __global__ __launch_bounds__(256, 4) void k_probe(const u3 *hot, const u3 *stepc
     if (need) le = g_L[(size_t)153 * rows * PT_DRAWS + day * rows * PT_DRAWS + li];
     acc += lb + le;
 #endif
+#if PROBE_TABLE != 3
     const float4 wb = g_W8[wi * 2];
     float4 we = make_float4(0.f, 0.f, 0.f, 0.f);
     if (need) we = g_W8[wi * 2 + 1];
     acc += wb.x * 0.5f + wb.y * 0.25f + wb.z * 0.125f + wb.w + we.x + we.y * 0.5f + we.z * 0.25f + we.w * 0.125f;
+#else
+    (void)wi;
+#endif
   }
 #endif
   const int p = lane & 7, g = lane >> 3;
@@ -340,7 +353,7 @@ int main() {
 #ifdef PROBE_TABLE
   {
     float *L; float4 *W8;
-    const size_t lbytes = (size_t)153 * R * 100 * 8;
+    const size_t lbytes = (size_t)153 * R * 100 * (PROBE_TABLE == 3 ? 32 : 8);  // =3: 16 B per head
     CHECK(hipMalloc(&L, lbytes)); CHECK(hipMalloc(&W8, (size_t)S * 32));
     CHECK(hipMemset(L, 0x3c, lbytes)); CHECK(hipMemset(W8, 0x3c, (size_t)S * 32));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_L), &L, sizeof(L))); CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_W8), &W8, sizeof(W8)));
