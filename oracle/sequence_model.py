@@ -118,6 +118,7 @@ class HandleModel:
         self.lock = False          # W2A_Q_LOCKSTEP
         self.bound, self.bound_known, self.foreign, self.auto_note = 0, 0, False, None
         self.graph_canon = self.graph_packed = self.graph_autoreset = False
+        self.graph_note = None
         self.pk_valid, self.canon_valid, self.poisoned = False, True, False
         self.order_set = False
         self.rm_valid = False
@@ -223,6 +224,8 @@ class HandleModel:
             self.bound = max(b, prev)
         if self.auto_note is not None:  # the handle's autoreset parameters go on handing out their budgets
             self._note_budgets(*self.auto_note)
+        if self.graph_note is not None:  # ... and so do the ones a recorded autoreset step was captured with
+            self._note_budgets(*self.graph_note)
 
     def _note_launch_reset(self, masked):
         """launch_reset for from_tuples != 2 (bk_reset + bk_end_call)."""
@@ -339,7 +342,7 @@ class HandleModel:
     def expect_step_kernel(self, flags_autoreset: bool, capturing: bool = False) -> int:
         """bk_step's plan: 0 k_step, 1 k_step64 on the canonical words, 2 k_step64 on the mirror; -1 refused (a capture
         that would have to record a conversion of the state's form)."""
-        packed = (self._wide() and not self.pm and not flags_autoreset and self.step_kernel != "unpacked" and self._can_pack())
+        packed = self._wide() and not self.pm and self.step_kernel != "unpacked" and self._can_pack()  # autoreset or not
         if capturing:
             if packed and not self.pk_valid:
                 packed = False
@@ -358,8 +361,12 @@ class HandleModel:
                 self.graph_packed = True
             else:
                 self.graph_canon = True
-                if flags_autoreset:
-                    self.graph_autoreset = True
+            if flags_autoreset:  # replays go on drawing budgets with the parameters of this moment
+                self.graph_autoreset = True
+                self.graph_note = self.auto_note if self.graph_note is None else (
+                    max(self.graph_note[0], self.auto_note[0]),
+                    BUDGET_CENTERED if BUDGET_CENTERED in (self.graph_note[1], self.auto_note[1]) else self.auto_note[1],
+                    int(bool(self.graph_note[2]) or bool(self.auto_note[2])))
         nxt = self.known_day + 1 if (not flags_autoreset and self.known_day >= 0 and self.known_day + 1 < self.uni_nd) else -1
         if self.any_graph:
             nxt = -1

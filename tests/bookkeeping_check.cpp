@@ -8,7 +8,7 @@
 //
 // Two drivers over the same operations:
 //   random      bookkeeping_check <sequences> <ops per sequence> <seed>      six envs, free parameters
-//   exhaustive  bookkeeping_check --bfs [max depth, 0 = to closure]          breadth-first walk of the ABSTRACT state space
+//   exhaustive  bookkeeping_check --bfs | --bfs-full [max depth, 0 = closure] breadth-first walk of the ABSTRACT state space
 //               to closure, two envs, episodes of two days (one in the budgets walk), as two walks: "forms" = every flag of W2aBook about the two
 //               forms of the state, lock step, recorded graphs and the validity of column grouping / visiting order / tile
 //               list / row counts x what is really current x the day structure of the batch x the graphs recorded (budgets
@@ -16,7 +16,10 @@
 //               sticky) of the envs x reset / autoreset parameters, on the invariant every use of the 16-bit mirror rests
 //               on: the handle's bound is never below a budget the buffer holds. Every operation with every parameter
 //               and every outcome of its internal choices from every reachable state; prints the number of reachable
-//               states. Nothing is sampled.
+//               states. Nothing is sampled. --bfs-full adds recorded autoreset steps and their replays (which keep drawing
+//               budgets with the parameters they were recorded with) to the budgets walk: 7.8 M states, four minutes
+//               without sanitizers -- run once per change of the budget rules (profiles/r05/bookkeeping_bfs_full.log),
+//               not in the suite.
 //
 // The entry points below restate, call for call, what csrc/w2a_kernels.hip / w2a_step_dispatch.hip.h do around their
 // kernel launches (each names the function it follows); a launch becomes "reads form X" / "writes form X".
@@ -85,7 +88,8 @@ struct Chooser {
 };
 
 struct Cfg { int64_t budget_kw; int mode; int sticky; };  // autoreset / reset parameters (w2a_set_autoreset)
-enum { G_PACKED = 1, G_CANON = 2, G_CANON_AUTO_SAME = 4, G_CANON_AUTO_NEXT = 8 };
+enum { G_PACKED = 1, G_CANON = 2, G_CANON_AUTO_SAME = 4, G_CANON_AUTO_NEXT = 8, G_PACKED_AUTO_SAME = 16, G_PACKED_AUTO_NEXT = 32 };
+static const int G_ANY_PACKED = G_PACKED | G_PACKED_AUTO_SAME | G_PACKED_AUTO_NEXT;
 
 struct World {
   int ne = NE;
@@ -105,6 +109,7 @@ struct World {
   bool has_autoreset = false;
   Cfg acfg{-1, 0, 1};
   int graphs = 0;        // kinds of recorded step (G_*)
+  Cfg gcfg[6];           // the autoreset parameters each kind was recorded with (kernel arguments: a replay keeps them)
   int64_t unstated = 0;  // largest budget handed over in device memory that no w2a_set_budget_bound has covered yet
   // ---- the handle
   W2aBook bk;
@@ -220,7 +225,7 @@ static void check_invariants(World &w) {
       REQUIRE(w, w.budget[i] <= w.bk.budget_bound && w.sticky[i] <= w.bk.budget_bound,
               "packed budgets: the handle's budget bound is below a budget (current or sticky) the state buffer holds");
   // a replay may come between any two API calls: what a recorded kernel would step must be current (or poisoned)
-  if (w.graphs & G_PACKED)
+  if (w.graphs & G_ANY_PACKED)
     REQUIRE(w, w.pk_day_val == POISON || (w.packed_id == w.latest && truly_uniform(w) && w.pk_day_val == w.day[0]),
             "unsafe replay: a recorded packed step would step a mirror that is neither current nor poisoned");
   if (w.graphs & (G_CANON | G_CANON_AUTO_SAME | G_CANON_AUTO_NEXT))
@@ -285,24 +290,38 @@ static void api_set_autoreset(World &w, const Cfg &c) {  // w2a_set_autoreset
 static void advance(World &w, int i) {  // one day of env.py:256-260
   if (w.day[i] + 1 >= w.nd[i]) w.fin[i] = true; else w.day[i]++;
 }
-static void packed_kernel(World &w, const char *who) {  // k_step64<..., PACKED>: eager or replayed
+static void new_episode(World &w, int i, const Cfg &c);
+// k_step64<..., PACKED[, AUTORESET]>: eager or replayed. In lock step the envs finish, and restart, together.
+static int kind_index(int kind) { int i = 0; while ((1 << i) != kind) ++i; return i; }
+static void packed_kernel(World &w, bool autoreset, bool next_step, const char *who, const Cfg *cfg = nullptr) {
+  const Cfg &ac = cfg ? *cfg : w.acfg;
   if (w.pk_day_val == POISON) { note(w, "    (poisoned mirror: W2A_ST_STALE_GRAPH, nothing stepped)"); return; }
   REQUIRE(w, w.packed_id == w.latest, (std::string("stale read: ") + who + " reads a mirror that is not current").c_str());
   REQUIRE(w, truly_uniform(w) && w.pk_day_val == w.day[0] && w.nd[0] == w.bk.uni_nd,
           "false lock step: the packed step kernel finds a day / length in the mirror the envs are not on");
   for (int i = 0; i < w.ne; ++i) REQUIRE(w, w.budget[i] <= 65535, "packed budgets: budget above 65535 in the 16-bit mirror");
   REQUIRE(w, w.static_ok, "packed form used although the tables forbid it");
-  for (int i = 0; i < w.ne; ++i) advance(w, i);
-  w.pk_day_val = w.day[0];  // the owning wave writes the tile's day word back
+  bool changed = false;
+  for (int i = 0; i < w.ne; ++i) {
+    if (autoreset && next_step && w.fin[i]) { new_episode(w, i, ac); changed = true; continue; }
+    advance(w, i);
+    if (autoreset && !next_step && w.fin[i]) { new_episode(w, i, ac); changed = true; }
+  }
+  if (changed) {  // the epilogue packs the new episodes' words itself
+    w.epoch = ++w.clock;
+    for (int i = 0; i < w.ne; ++i) REQUIRE(w, w.budget[i] <= 65535, "packed budgets: an in-kernel autoreset packs a budget above 65535");
+  }
+  w.pk_day_val = w.day[0];  // the owning wave writes the tile's day word back (0 after a restart)
   w.packed_id = w.latest = ++w.clock;
 }
-static void canon_kernel(World &w, bool autoreset, bool next_step, const char *who) {  // k_step / k_step64 on the canonical words
+static void canon_kernel(World &w, bool autoreset, bool next_step, const char *who, const Cfg *cfg = nullptr) {  // k_step / k_step64 on the canonical words
+  const Cfg &ac = cfg ? *cfg : w.acfg;
   read_canon(w, who);
   bool changed = false;
   for (int i = 0; i < w.ne; ++i) {
-    if (autoreset && next_step && w.fin[i]) { new_episode(w, i, w.acfg); changed = true; continue; }
+    if (autoreset && next_step && w.fin[i]) { new_episode(w, i, ac); changed = true; continue; }
     advance(w, i);  // a finished env repeats its last day (env.py:256: done again)
-    if (autoreset && !next_step && w.fin[i]) { new_episode(w, i, w.acfg); changed = true; }
+    if (autoreset && !next_step && w.fin[i]) { new_episode(w, i, ac); changed = true; }
   }
   if (changed) w.epoch = ++w.clock;
   write_canon(w);
@@ -319,24 +338,29 @@ static void api_step(World &w, bool wide, bool autoreset, bool next_step, bool g
     end_call(w);
     return;
   }
-  if (p.kernel == W2A_BK_STEP_PACKED) REQUIRE(w, !given && !autoreset, "the packed kernel has no REWARD_GIVEN / AUTORESET variant");
+  if (p.kernel == W2A_BK_STEP_PACKED) REQUIRE(w, !given, "the packed kernel has no REWARD_GIVEN variant");
   if (capturing) {  // recorded, not executed
     REQUIRE(w, p.converted == 0, "a conversion of the state's form was recorded into a hipGraph");
-    w.graphs |= p.kernel == W2A_BK_STEP_PACKED ? G_PACKED : (!autoreset ? G_CANON : (next_step ? G_CANON_AUTO_NEXT : G_CANON_AUTO_SAME));
+    int kind;
+    if (p.kernel == W2A_BK_STEP_PACKED) kind = !autoreset ? G_PACKED : (next_step ? G_PACKED_AUTO_NEXT : G_PACKED_AUTO_SAME);
+    else kind = !autoreset ? G_CANON : (next_step ? G_CANON_AUTO_NEXT : G_CANON_AUTO_SAME);
+    w.graphs |= kind;
+    w.gcfg[kind_index(kind)] = w.acfg;  // (one recording per kind is kept: a later one of the same kind replaces it)
     if (p.kernel == W2A_BK_STEP_PACKED) end_call(w);
     return;
   }
   if (p.kernel == W2A_BK_STEP_PACKED) {
     REQUIRE(w, w.pk_day_val != POISON, "the packed step kernel is launched on a poisoned mirror");
-    packed_kernel(w, "the packed step kernel");
+    packed_kernel(w, autoreset, next_step, "the packed step kernel");
   } else {
     canon_kernel(w, autoreset, next_step, "the step kernel");
   }
   end_call(w);
 }
 static void api_graph_replay(World &w, int kind) {  // hipGraphLaunch of a recorded step kernel: no host bookkeeping runs
-  if (kind == G_PACKED) packed_kernel(w, "a replayed packed step kernel");
-  else canon_kernel(w, kind != G_CANON, kind == G_CANON_AUTO_NEXT, "a replayed canonical step kernel");
+  const Cfg *c = &w.gcfg[kind_index(kind)];
+  if (kind & G_ANY_PACKED) packed_kernel(w, kind != G_PACKED, kind == G_PACKED_AUTO_NEXT, "a replayed packed step kernel", c);
+  else canon_kernel(w, kind != G_CANON, kind == G_CANON_AUTO_NEXT, "a replayed canonical step kernel", c);
 }
 static void api_rollout(World &w, int32_t n_steps, bool fixes) {  // w2a_rollout
   StubDev d{w};
@@ -496,6 +520,7 @@ static void apply(World &w, const Op &o) {
   check_invariants(w);
 }
 static void init_world(World &w, Chooser *rng, int32_t uni_nd, int32_t b0_max, bool static_ok) {
+  for (Cfg &c : w.gcfg) c = Cfg{-1, 0, 1};
   w.rng = rng; w.uni_nd = uni_nd; w.b0_max = b0_max; w.static_ok = static_ok;
   bk_init(w.bk, static_ok, uni_nd, b0_max);
   for (int i = 0; i < w.ne; ++i) { w.day[i] = 0; w.nd[i] = 1; w.fin[i] = true; w.budget[i] = 0; w.sticky[i] = -1; w.episode[i] = -1; }
@@ -545,7 +570,7 @@ static void run_sequence(uint64_t seed, int n_ops) {
     else if (u < 93) {
       o.kind = OP_STEP; o.capturing = true;
       o.wide = rng.coin(70); o.autoreset = w.has_autoreset && rng.coin(40); o.next = rng.coin(40); o.unpacked = rng.coin(10);
-    } else if (u < 97) { o.kind = OP_REPLAY; o.graph = 1 << rng.below(4); }
+    } else if (u < 97) { o.kind = OP_REPLAY; o.graph = 1 << rng.below(6); }
     else if (u < 99) { o.kind = OP_SET_AUTORESET; o.cfg = random_cfg(rng); }
     else o.kind = OP_ORDER_ATTACH;
     apply(w, o);
@@ -566,18 +591,22 @@ static std::string key_of(const World &w) {
   for (int64_t v : {(int64_t)b.pk_valid, (int64_t)b.canon_valid, (int64_t)b.lock, (int64_t)b.uni_t, b.budget_bound, b.budget_bound_known,
                     (int64_t)b.foreign, (int64_t)b.has_auto, b.auto_cand, (int64_t)b.auto_centered, (int64_t)b.auto_sticky,
                     (int64_t)b.graph_canon, (int64_t)b.graph_packed, (int64_t)b.graph_autoreset, (int64_t)b.poisoned,
+                    b.graph_cand, (int64_t)b.graph_centered, (int64_t)b.graph_sticky,
                     (int64_t)b.perm_valid, (int64_t)b.has_order, (int64_t)b.rm_valid, (int64_t)b.has_order_ws, (int64_t)b.hist_valid})
     put(v);  // last_step_kernel / last_rollout_kernel: outputs only
   for (int i = 0; i < w.ne; ++i) { put(w.day[i]); put(w.nd[i]); put(w.fin[i]); put(w.budget[i]); put(w.sticky[i]); }
   put(w.canon_id == w.latest); put(w.packed_id == w.latest);
   put(w.pk_day_val == POISON ? 0 : (truly_uniform(w) && w.pk_day_val == w.day[0] ? 1 : 2));
   put(w.perm_for == w.epoch); put(w.rm_for == w.epoch && w.rm_order_gen == w.order_gen); put(w.hist_for == w.epoch);
+  for (int k : {2, 3, 4, 5})  // recorded autoreset kinds: the parameters their replays draw with
+    if (w.graphs & (1 << k)) { put(w.gcfg[k].budget_kw); put(w.gcfg[k].mode); put(w.gcfg[k].sticky); }
   put(w.unstated); put(w.order_exists); put(w.has_autoreset); put(w.acfg.budget_kw); put(w.acfg.mode); put(w.acfg.sticky); put(w.graphs);
   return k;
 }
 // walk 0 "budgets": every operation that touches budget knowledge (+ plain / autoreset steps, so that episodes end, restart
 // inside the kernel and get packed). walk 1 "forms": everything about forms, lock step, graphs and grouping, with one reset
 // configuration and small budgets -- known, or handed over in device memory with / without a stated bound.
+static bool g_full = false;  // --bfs-full: the budgets walk also records and replays autoreset steps (7.8 M states, minutes)
 static std::vector<Op> all_ops(int walk) {
   std::vector<Op> v;
   std::vector<Cfg> cfgs;
@@ -588,6 +617,10 @@ static std::vector<Op> all_ops(int walk) {
   } else cfgs.push_back(Cfg{-1, 0, 1});
   if (walk == 0) {
     for (int ar = 0; ar < 3; ++ar) { Op o; o.kind = OP_STEP; o.wide = true; o.autoreset = ar > 0; o.next = ar == 2; v.push_back(o); }
+    if (g_full) {  // --bfs-full: a recorded autoreset step keeps the parameters it was recorded with, its replays go on
+      Op o; o.kind = OP_STEP; o.wide = true; o.autoreset = true; o.capturing = true; v.push_back(o);  // drawing budgets with
+      for (int g : {(int)G_CANON_AUTO_SAME, (int)G_PACKED_AUTO_SAME}) { Op r; r.kind = OP_REPLAY; r.graph = g; v.push_back(r); }  // them
+    }
   } else {
     for (int form = 0; form < 3; ++form)      // 4-lanes-per-env kernel; 64-envs-per-wave; the latter with W2A_STEP_UNPACKED
       for (int ar = 0; ar < 3; ++ar)          // none, same-step, next-step autoreset
@@ -621,7 +654,9 @@ static std::vector<Op> all_ops(int walk) {
   for (int shape = 0; shape < (walk == 0 ? 4 : 2); ++shape)
     for (int tell = 0; tell < (walk == 0 ? 2 : 1); ++tell) { Op o; o.kind = OP_INVALIDATE; o.shape = shape; o.tell = tell; v.push_back(o); }
   if (walk == 1)
-    for (int g : {(int)G_PACKED, (int)G_CANON, (int)G_CANON_AUTO_SAME, (int)G_CANON_AUTO_NEXT}) { Op o; o.kind = OP_REPLAY; o.graph = g; v.push_back(o); }
+    for (int g : {(int)G_PACKED, (int)G_CANON, (int)G_CANON_AUTO_SAME, (int)G_CANON_AUTO_NEXT, (int)G_PACKED_AUTO_SAME, (int)G_PACKED_AUTO_NEXT}) {
+      Op o; o.kind = OP_REPLAY; o.graph = g; v.push_back(o);
+    }
   if (walk == 0)
     for (const Cfg &c : cfgs) { Op o; o.kind = OP_SET_AUTORESET; o.cfg = c; v.push_back(o); }
   for (int64_t bd : {(int64_t)-1, (int64_t)-2, (int64_t)100000}) { Op o; o.kind = OP_SET_BOUND; o.bound = bd; v.push_back(o); }
@@ -687,7 +722,10 @@ static int run_bfs(int max_depth) {
 }
 
 int main(int argc, char **argv) {
-  if (argc > 1 && !strcmp(argv[1], "--bfs")) return run_bfs(argc > 2 ? atoi(argv[2]) : 0);
+  if (argc > 1 && (!strcmp(argv[1], "--bfs") || !strcmp(argv[1], "--bfs-full"))) {
+    g_full = !strcmp(argv[1], "--bfs-full");
+    return run_bfs(argc > 2 ? atoi(argv[2]) : 0);
+  }
   const int n_seq = argc > 1 ? atoi(argv[1]) : 2000;
   const int n_ops = argc > 2 ? atoi(argv[2]) : 120;
   const uint64_t seed = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1;

@@ -66,8 +66,7 @@ MUTANTS = [
     ("a new visiting order keeps the old tile list", "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; b.rm_valid = 0; }",
      "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; }"),
     ("reset keeps the matrix-core rollout's tile list", "  b.rm_valid = 0;  // new episodes: the feature-row tile list of the matrix-core rollout is stale\n", "\n"),
-    ("a REWARD_GIVEN step runs packed", "bool packed = wide_wanted && !given && !autoreset", "bool packed = wide_wanted && !autoreset"),
-    ("an autoreset step runs packed", "!given && !autoreset && !unpacked_flag && bk_can_pack(b);", "!given && !unpacked_flag && bk_can_pack(b);"),
+    ("a REWARD_GIVEN step runs packed", "bool packed = wide_wanted && !given && !unpacked_flag", "bool packed = wide_wanted && !unpacked_flag"),
     ("a rollout does not bring the canonical words up to date", "  const int32_t day = b.uni_t;\n  bk_ensure_canonical(b, d);", "  const int32_t day = b.uni_t;"),
     ("a rollout leaves the mirror marked current", "  bk_ensure_canonical(b, d);\n  bk_canonical_modified(b, true);\n  b.uni_t = (day >= 0",
      "  bk_ensure_canonical(b, d);\n  b.uni_t = (day >= 0"),
@@ -81,7 +80,9 @@ MUTANTS = [
     ("after a recorded packed step, nothing keeps the mirror current", "  if (!b.graph_packed) return;\n", "  return;\n"),
     ("a mirror that cannot be kept current is not poisoned", "  } else if (!b.poisoned) {\n    d.poison_mirror();\n    b.poisoned = 1;\n  }", "  }"),
     ("the mirror is re-packed although the batch cannot be packed", "  if (bk_can_pack(b)) {  // the canonical words were modified", "  if (true) {  //"),
-    ("a recorded autoreset step is not remembered", "      if (autoreset) b.graph_autoreset = 1;\n", "\n"),
+    ("a recorded autoreset step is not remembered", "      b.graph_autoreset = 1;\n", "\n"),
+    ("the parameters a recorded autoreset step draws budgets with are forgotten by the next statement",
+     "  if (b.graph_autoreset) bk_note_budgets(b, b.graph_cand, b.graph_centered != 0, b.graph_sticky != 0);\n", "\n"),
     ("an in-kernel autoreset keeps the row counts", "    b.hist_valid = 0;\n  }\n  if (capturing) {", "  }\n  if (capturing) {"),
     ("a relabelling keeps the per-env ranks", "  b.hist_valid = 0;  // ... and so are the per-env ranks inside the feature rows\n", "\n"),
     ("a masked reset leaves the row counts valid", "b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;",

@@ -1471,6 +1471,56 @@ def test_step_is_hipgraph_capturable(dev):
     cap.close()
 
 
+@pytest.mark.parametrize("autoreset", ["same_step", "next_step"])
+def test_packed_step_with_the_autoreset_inside_the_kernel(dev, autoreset):
+    """A lock-step batch whose episodes restart INSIDE the step kernel (lockstep=False by choice: what a loop recorded
+    into a hipGraph needs, since the host cannot launch a reset between two recorded steps) still streams the packed
+    16-B state: envs that are on one day finish, and restart, together, tile by tile (round 5). Bit for bit the
+    canonical-form kernel (step_kernel='unpacked') through three episode boundaries, eagerly and as a recorded block."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007, 2008], n_samples=6, n_days=12, seed=77, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    n = 131072 + 19
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, autoreset=autoreset, lockstep=False)
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, autoreset=autoreset, lockstep=False,
+                        step_kernel="unpacked")
+    oa, _ = A.reset(seed=3)
+    ob, _ = B.reset(seed=3)
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device=dev).manual_seed(11)
+    acts = [(torch.rand(n, device=dev, generator=g) < 0.3).to(torch.int32) for _ in range(7)]
+    for t in range(3 * 12 + 5):
+        ra, rb = A.step(acts[t % 7]), B.step(acts[t % 7])
+        for x, y in zip(ra[:3], rb[:3]):
+            assert torch.equal(x, y), t
+        assert A.last_step_kernel == "k_step64<packed>" and B.last_step_kernel == "k_step64", t
+        assert torch.equal(A._final_return, B._final_return)
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sa["episode_no"].min()) >= 2 and A.check_status() == 0 and B.check_status() == 0
+    # recorded: 7 packed autoreset steps per graph, replayed across two more episode boundaries
+    A.step(acts[0]); B.step(acts[0])  # (the read-back above left both forms current; any step puts A on the mirror again)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for a in acts:
+            A.step(a)
+    assert A.last_step_kernel == "k_step64<packed>" and A.packed_state
+    for rep in range(4):
+        graph.replay()
+        for a in acts:
+            o, r, d, _, _ = B.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(A._obs, o) and torch.equal(A._reward, r) and torch.equal(A._done_bool, d), rep
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert A.check_status() == 0
+    A.close()
+    B.close()
+
+
 def test_other_schema_parity(dev):
     """A schema with one exogenous feature fewer (n_obs = 28): kernels, observation order and rewards still
     match the oracle, which derives everything from the column / key names as well."""

@@ -57,7 +57,9 @@ struct W2aBook {
                          // the batch can no longer be packed (lock step lost, budgets out of sight), its day words are
                          // POISONED so that a replay raises W2A_ST_STALE_GRAPH instead of stepping stale state
   int graph_autoreset;   // a recorded step carried W2A_STEP_AUTORESET: replays re-draw episodes at any time -- a column
-                         // grouping, a tile list, row counts are never again reported valid
+                         // grouping, a tile list, row counts are never again reported valid -- and draw their budgets
+  int64_t graph_cand;    // with the w2a_set_autoreset parameters of the moment they were recorded (kernel arguments),
+  int graph_centered, graph_sticky;  // whatever is set or stated later: the largest / widest of them, kept like auto_*
   int poisoned;          // the mirror's day words hold the poison value
   int perm_valid;        // the column grouping (w2a_group_by_column) belongs to the episodes the envs hold
   int has_order;         // a visiting order exists (any permutation is correct; it may be stale = unsorted)
@@ -75,6 +77,7 @@ static inline void bk_init(W2aBook &b, bool pk_static_ok, int32_t uni_nd, int32_
   b.lock = 0; b.uni_t = -1; b.uni_nd = uni_nd; b.b0_max = b0_max;
   b.budget_bound = 0; b.budget_bound_known = 0; b.foreign = 0;
   b.graph_canon = 0; b.graph_packed = 0; b.graph_autoreset = 0; b.poisoned = 0;
+  b.graph_cand = 0; b.graph_centered = 0; b.graph_sticky = 0;
   b.has_auto = 0; b.auto_cand = 0; b.auto_centered = 0; b.auto_sticky = 0;
   b.perm_valid = 0; b.has_order = 0; b.rm_valid = 0; b.has_order_ws = 0; b.hist_valid = 0;
   b.last_step_kernel = -1; b.last_rollout_kernel = -1;
@@ -137,8 +140,10 @@ static inline void bk_set_budget_bound(W2aBook &b, int64_t bound) {
     if (prev == W2A_BK_UNKNOWN) return;
     b.budget_bound = bound > prev ? bound : prev;  // budgets of earlier episodes may live on as sticky budgets
   }
-  // the statement is about the budgets in the buffer; the autoreset parameters of the handle go on handing out theirs
+  // the statement is about the budgets in the buffer; the autoreset parameters of the handle go on handing out theirs --
+  // and so do the ones a recorded autoreset step was captured with, on every replay
   if (b.has_auto) bk_note_budgets(b, b.auto_cand, b.auto_centered != 0, b.auto_sticky != 0);
+  if (b.graph_autoreset) bk_note_budgets(b, b.graph_cand, b.graph_centered != 0, b.graph_sticky != 0);
 }
 // w2a_set_autoreset: the parameters in-kernel autoresets draw budgets with from now on
 static inline void bk_set_autoreset(W2aBook &b, int64_t cand, bool centered, bool sticky) {
@@ -196,7 +201,8 @@ static inline BkStepPlan bk_step(W2aBook &b, Dev &d, bool wide_wanted, bool auto
                                  bool capturing) {
   BkStepPlan p;
   p.kernel = W2A_BK_STEP_CLASSIC; p.uni_nd = b.uni_nd; p.converted = 0;
-  bool packed = wide_wanted && !given && !autoreset && !unpacked_flag && bk_can_pack(b);
+  // (an in-kernel autoreset does not stand in the way: a batch in lock step restarts together, tile by tile)
+  bool packed = wide_wanted && !given && !unpacked_flag && bk_can_pack(b);
   if (capturing) {
     // no conversion launch may be recorded: a replay would convert again, from words the replayed steps have outdated
     if (packed && !b.pk_valid) packed = false;
@@ -209,9 +215,11 @@ static inline BkStepPlan bk_step(W2aBook &b, Dev &d, bool wide_wanted, bool auto
   }
   if (capturing) {
     if (packed) b.graph_packed = 1;
-    else {
-      b.graph_canon = 1;
-      if (autoreset) b.graph_autoreset = 1;
+    else b.graph_canon = 1;
+    if (autoreset) {  // (w2a_step refuses W2A_STEP_AUTORESET before w2a_set_autoreset: has_auto holds)
+      b.graph_autoreset = 1;
+      if (b.auto_cand > b.graph_cand) b.graph_cand = b.auto_cand;
+      b.graph_centered |= b.auto_centered; b.graph_sticky |= b.auto_sticky;
     }
   }
   // the day every env is on after this call, while the host can know it: a plain step moves all of them to the next
@@ -242,9 +250,10 @@ static inline BkStepPlan bk_step(W2aBook &b, Dev &d, bool wide_wanted, bool auto
 // The launch bk_step planned did not happen (hipLaunchKernel failed): the state is what it was before the call, except
 // that a conversion which did run has left BOTH forms current. `before` = the handle's book before bk_step.
 static inline void bk_step_rollback(W2aBook &b, const W2aBook &before, const BkStepPlan &p) {
-  const int gc = b.graph_canon, gp = b.graph_packed, ga = b.graph_autoreset;  // conservative: keep what was recorded
+  const W2aBook after = b;  // conservative: keep what was recorded
   b = before;
-  b.graph_canon = gc; b.graph_packed = gp; b.graph_autoreset = ga;
+  b.graph_canon = after.graph_canon; b.graph_packed = after.graph_packed; b.graph_autoreset = after.graph_autoreset;
+  b.graph_cand = after.graph_cand; b.graph_centered = after.graph_centered; b.graph_sticky = after.graph_sticky;
   if (bk_any_graph(b)) b.uni_t = -1;
   if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }
   if (p.converted == 2) b.canon_valid = 1;

@@ -116,9 +116,11 @@ __device__ __forceinline__ void st1_sc1(void *p, uint32_t v) {
 // One 64-env tile of one wave, phases A..C, from the tile's already loaded state words and action.
 // REWARD_GIVEN: a.reward already holds today's reward (w2a_posterior_mean_reward ran on the same state and actions):
 // no coefficient gather and no logits here, the rest of env.py:238-262 as usual.
-// AUTORESET: same-step autoreset for batches that are not in lock step (masked resets, ragged episode lengths): an env
-// whose terminal step has just run draws its next episode and gets that episode's first observation, as in
-// k_step<AUTORESET> -- here as a rare per-lane epilogue (one env-day in n_days), on the canonical state words.
+// AUTORESET: in-kernel autoreset (batches that are not in lock step: masked resets, ragged episode lengths; loops recorded
+// into a hipGraph, where the host cannot launch a reset kernel between two steps): an env whose terminal step has just run
+// draws its next episode and gets that episode's first observation, as in k_step<AUTORESET> -- here as a rare per-lane
+// epilogue (one env-day in n_days). With PACKED (a lock-step batch: all envs of a tile restart in the same launch) the
+// epilogue also writes the mirror's words of the new episode and puts the tile's day word back to 0.
 // FIXES: the corrected-semantics flags of a.tb.fixes (W2A_FIX_*: Q1 agent's 14-day count into the historical column,
 // Q3 true lag, Q5 live over-budget penalty, Q6 observation of the day the next action applies to), as in k_step<..., FIXES>.
 template <bool WRITE_OBS, bool REWARD_GIVEN, bool PACKED, bool AUTORESET = false, bool FIXES = false>
@@ -354,6 +356,11 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
         if (ep.bad) atomicOr(a.status, (int)W2A_ST_BAD_EPISODE);
         store_episode(a.st, e, make_uint4(ep.ep_row, ep.ep_w, (uint32_t)ep.sticky, cold.w + 1),
                       make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
+        if (PACKED) {  // the mirror's words of the new episode, over the ones phase C has just written (k_pack_state's packing)
+          a.st.pk_hot[e] = make_uint2(pk_pack_hot(0u, 0u, 0u, 0u), __float_as_uint(0.0f));
+          a.st.pk_c[e] = make_uint2(((uint32_t)ep.budget & 0xFFFFu) | (W_COL(ep.ep_w) << 16),
+                                    (ep.ep_row & 0x3FFFFFu) | (W_SAMPLE(ep.ep_w) << 22));
+        }
         if (WRITE_OBS) {
           float *row = reinterpret_cast<float *>(a.obs) + (size_t)e * n_obs;
           const float4 *xr = a.tb.X + (size_t)ep.ep_row * (ROWF / 4);  // day 0
@@ -371,6 +378,8 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
           }
         }
       }
+      // packed form = lock step: the envs of a tile finish, and restart, together -- the tile is on day 0 again
+      if (PACKED && lane == 0) a.st.pk_day[wave_env0 >> 6] = 0u;
     }
   }
 }

@@ -69,7 +69,13 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
     if (plan.kernel == W2A_BK_STEP_PACKED) {
       // lock-step mirror (StateArrays::pk_hot / pk_c): 20 B in and 8 B out of per-env state instead of 28 and 12
       a.uni_nd = plan.uni_nd;
-      if (env->tb.fixes) {  // corrected-semantics flags: their own variants, the faithful kernels carry none of the code
+      if (autoreset) {  // a lock-step batch whose episodes restart inside the kernel (recorded loops, lockstep=False by choice)
+        if (env->tb.fixes) {
+          if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, true, true>), grid64, block, 0, s, a);
+          else hipLaunchKernelGGL((k_step64<true, false, true, true, true>), grid64, block, 0, s, a);
+        } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, true>), grid64, block, 0, s, a);
+        else hipLaunchKernelGGL((k_step64<true, false, true, true>), grid64, block, 0, s, a);
+      } else if (env->tb.fixes) {  // corrected-semantics flags: their own variants, the faithful kernels carry none of the code
         if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true, false, true>), grid64, block, 0, s, a);
         else hipLaunchKernelGGL((k_step64<true, false, true, false, true>), grid64, block, 0, s, a);
       } else if (no_obs) hipLaunchKernelGGL((k_step64<false, false, true>), grid64, block, 0, s, a);
