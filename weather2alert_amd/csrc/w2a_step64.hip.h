@@ -84,7 +84,7 @@ struct S64WaveT {
 #define W2A_S64_SKIP_EFF 1  // skip the effectiveness dot product in rounds where no env alerts today (A/B)
 #endif
 #ifndef W2A_S64_NT_STATE
-#define W2A_S64_NT_STATE 0  // A/B: bit 0 = hot3, bit 1 = stepc loaded non-temporally
+#define W2A_S64_NT_STATE 0  // A/B: bit 0 = hot3, bit 1 = stepc, bit 2 = the packed mirror's words loaded non-temporally
 #endif
 typedef uint32_t v3u __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void st16_sc1(void *p, v4f v) {
@@ -388,8 +388,14 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
 // day on every replay), the episode length from the kernel arguments; the canonical words are rebuilt in registers so
 // that the tile code is shared
 __device__ __forceinline__ void s64_load_packed(const StepArgs &a, uint32_t e, uint32_t day, u3 &h, u3 &c, int32_t &act) {
+#if W2A_S64_NT_STATE & 4  // A/B: the mirror's words loaded non-temporally (streamed once per step: no reason to keep them in L2)
+  const v2u phv = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(&a.st.pk_hot[e]));
+  const v2u pcv = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(&a.st.pk_c[e]));
+  const uint2 ph = make_uint2(phv.x, phv.y), pc = make_uint2(pcv.x, pcv.y);
+#else
   const uint2 ph = a.st.pk_hot[e];
   const uint2 pc = a.st.pk_c[e];
+#endif
   h.a = pack_d0(day, PK_USED(ph.x), PK_STREAK(ph.x), PK_HIST(ph.x) & 1u, 0u);
   h.b = pack_d1(PK_HIST(ph.x), (uint32_t)a.uni_nd, PK_FIN(ph.x));
   h.c = ph.y;
