@@ -58,7 +58,9 @@ enum { W2A_ACT_I32 = 0, W2A_ACT_I64 = 1, W2A_ACT_U8 = 2 };
 enum {
   W2A_STEP_AUTORESET = 1, /* same-step autoreset with the device RNG (needs w2a_set_autoreset): envs whose terminal step
                              has just run draw their next episode inside the step kernel and return its first
-                             observation -- for batches that are not in lock step (both step kernels serve it) */
+                             observation -- for batches that are not in lock step, and for loops recorded into a
+                             hipGraph, where no reset can be launched between two steps (both step kernels serve it; a
+                             batch that IS in lock step restarts together and stays on the packed form) */
   W2A_STEP_NO_OBS = 2,    /* reward-only: skip the observation write */
   W2A_STEP_CLASSIC = 8,   /* force the 4-lanes-per-env kernel where the 64-envs-per-wave one would be chosen (same
                              results up to the order of the fp64 additions; for A/B measurements and tests) */
