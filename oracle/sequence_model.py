@@ -605,6 +605,7 @@ class HandleModel:
         self.known_day, self.lock = -1, False
         self.rm_valid = False
         self.pk_valid, self.canon_valid = False, True
+        self.poisoned = False  # the restored buffer covers the mirror's day words: the handle poisons them again if it must
         self._end_call()
 
     def restore(self, d: dict):

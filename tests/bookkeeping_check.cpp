@@ -435,6 +435,7 @@ static void api_invalidate(World &w, bool tell, int shape) {
   }
   w.epoch = ++w.clock;
   write_canon(w);
+  w.pk_day_val = 0;  // the caller's copy covers the whole buffer, the mirror's day words included: some old day, not the poison
   bk_invalidate(w.bk);
   {  // w2a_invalidate scans the restored buffer itself (k_budget_scan): largest budget, current and sticky
     int64_t m = 0;

@@ -87,7 +87,9 @@ MUTANTS = [
     ("a relabelling keeps the per-env ranks", "  b.hist_valid = 0;  // ... and so are the per-env ranks inside the feature rows\n", "\n"),
     ("a masked reset leaves the row counts valid", "b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;",
      "b.hist_valid = (b.has_order_ws && !b.graph_autoreset) ? 1 : 0;"),
-    ("a restore keeps the row counts", "  b.hist_valid = 0;\n}\n\n#endif", "}\n\n#endif"),
+    ("a restore keeps the row counts", "  b.hist_valid = 0;\n  b.poisoned = 0;", "  b.poisoned = 0;"),
+    ("a restored buffer is taken to be still poisoned (round 5, GPU fuzz seed 505 sequence 357)",
+     "  b.poisoned = 0;  // the caller's copy covered the mirror's day words too", "  //"),
     ("another order workspace inherits the row counts", "{ b.has_order_ws = 1; b.hist_valid = 0; }", "{ b.has_order_ws = 1; }"),
     ("a failed launch after a conversion forgets that the mirror was rewritten",
      "  if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }", "  if (p.converted == 1) { b.pk_valid = 1; }"),

@@ -1521,6 +1521,70 @@ def test_packed_step_with_the_autoreset_inside_the_kernel(dev, autoreset):
     B.close()
 
 
+def test_packed_state_at_the_limits_of_its_bit_fields(dev):
+    """The lock-step mirror packs used / streak into 8 bits each, the budget into 16, the posterior draw into 10 and the day
+    into a tile word: tables at exactly those limits -- 255-day episodes, 1 024 draws, budget 65 535, an alert every day
+    (used and streak reach 254, the 14-day history is all ones) -- must still be bit-identical to the canonical-form kernel
+    and, on a sample, agree with the oracle; one more unit of budget (65 536) and the handle must not pack at all."""
+    from weather2alert_amd import HeatAlertVecEnv, _ffi
+
+    sd = synth.make_synth("linear", n_fips=6, years=[2006, 2007], n_samples=1024, n_days=255, seed=3, extra_confounder_fips=2)
+    ct = tables.compile_from_synth(sd)
+    assert ct.T == 255 and ct.n_samples == 1024
+    n = 131072 + 3
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="auto")
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="unpacked")
+    q = lambda e, what: e._lib.w2a_query(e._h, what)  # noqa: E731
+    A.reset(seed=1, options={"budget": 65535})
+    B.reset(seed=1, options={"budget": 65535})
+    assert q(A, _ffi.Q_PACKED_ELIGIBLE) == 1
+    idx = np.unique(np.concatenate([np.arange(0, n, 257), [n - 1]]))
+    it = torch.as_tensor(idx, device=dev)
+    st = {k: v[it].cpu().numpy() for k, v in A.state().items()}
+    assert int(st["sample"].max()) > 1000 and (st["budget"] == 65535).all()
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+    worst = 0.0
+    for t in range(255 + 3):  # the whole episode, the lock-step autoreset, three days of the next one
+        oa, ra, da, _, _ = A.step(ones)
+        ob, rb, db, _, _ = B.step(ones)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), t
+        if t < 255:
+            assert A.packed_state == (t != 254), t  # (the terminal step's call ends with the reset kernel: canonical)
+            obs_o, r_o, done_o, _ = V.step(np.ones(len(idx), np.int64))
+            worst = max(worst, float(np.abs(ra[it].cpu().numpy().astype(np.float64) - r_o).max()))
+            assert np.array_equal(da[it].cpu().numpy(), done_o)
+            if t < 254:
+                assert np.array_equal(oa[it].cpu().numpy(), obs_o.astype(np.float32)), t
+        if t == 253:  # the day before the terminal step: every counter at its largest
+            sa = A.state()
+            assert int(sa["used"].min()) == 254 and int(sa["streak"].min()) == 254 and int(sa["hist14"].min()) == 0x3FFF
+            assert q(A, _ffi.Q_PACKED_CURRENT) == 1  # (the read-back was a copy: the mirror stays current)
+    assert worst <= 1e-5, worst
+    assert torch.equal(A._final_return, B._final_return)
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert A.check_status() == 0 and B.check_status() == 0
+    A.close()
+    B.close()
+    # one more unit of budget does not fit 16 bits: no packed step, same results (fresh envs: a budget sticks, Q9)
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="auto")
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="unpacked")
+    A.reset(seed=2, options={"budget": 65536})
+    B.reset(seed=2, options={"budget": 65536})
+    assert q(A, _ffi.Q_PACKED_ELIGIBLE) == 0
+    for t in range(5):
+        oa, ra, _, _, _ = A.step(ones)
+        ob, rb, _, _, _ = B.step(ones)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and not A.packed_state
+    assert int(A.state()["budget"].min()) == 65536 and A.check_status() == 0 and B.check_status() == 0
+    print(f"packed limits: max |reward - oracle| = {worst:.2e}")
+    A.close()
+    B.close()
+
+
 def test_other_schema_parity(dev):
     """A schema with one exogenous feature fewer (n_obs = 28): kernels, observation order and rewards still
     match the oracle, which derives everything from the column / key names as well."""

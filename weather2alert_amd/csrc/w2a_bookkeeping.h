@@ -299,6 +299,9 @@ static inline void bk_invalidate(W2aBook &b) {
   b.pk_valid = 0; b.canon_valid = 1; b.lock = 0; b.uni_t = -1; b.perm_valid = 0;
   b.rm_valid = 0;  // feature rows may have changed behind the handle: the matrix-core rollout's tile list is stale
   b.hist_valid = 0;
+  b.poisoned = 0;  // the caller's copy covered the mirror's day words too: whatever they hold now, it is not the poison
+                   // (found by tools/sequence_fuzz.py, seed 505 sequence 357: a checkpoint restored over a poisoned
+                   // mirror brought real days back, and a replayed packed step stepped stale state instead of refusing)
 }
 
 #endif  // W2A_BOOKKEEPING_H
