@@ -278,19 +278,34 @@ static unsigned grid_for(int64_t n) {
 }
 
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
+  // arguments first: nothing below may fail for a reason the caller can fix once the bookkeeping has been told of the reset
+  if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
+  const W2aBook before = env->bk;
   {
     HipDev d{env, (hipStream_t)stream};
     bk_reset(env->bk, d, a.from_tuples == 2, a.mask != nullptr);
   }
   a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
   a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
-  if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
+  hipError_t e = hipSuccess;
   if (env->bk.hist_valid && a.from_tuples != 2) {  // whole-batch reset, order workspace attached: row counts and per-env ranks come with it
-    HIP_TRY(hipMemsetAsync(env->order_cnt, 0, 4 * (size_t)env->tb.S_w * env->tb.Y, (hipStream_t)stream));
+    e = hipMemsetAsync(env->order_cnt, 0, 4 * (size_t)env->tb.S_w * env->tb.Y, (hipStream_t)stream);
     a.order_cnt = env->order_cnt; a.order_rank = env->order_rank;
   }
-  hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
-  HIP_TRY(hipGetLastError());
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    // the reset did not happen: the state is what it was, except that a conversion bk_reset asked for (a masked reset or
+    // w2a_observe on the packed form) did run and left both forms current; derived structures are dropped (conservative)
+    const bool unpacked = !before.canon_valid && env->bk.canon_valid;
+    env->bk = before;
+    if (unpacked) env->bk.canon_valid = 1;
+    env->bk.hist_valid = 0; env->bk.perm_valid = 0; env->bk.rm_valid = 0;
+    end_call(env, (hipStream_t)stream);
+    return fail(W2A_ERR_HIP, "reset: launch failed: %s", hipGetErrorString(e));
+  }
   end_call(env, (hipStream_t)stream);
   return W2A_OK;
 }
