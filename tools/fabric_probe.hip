@@ -326,7 +326,13 @@ int main() {
   u3 *hot, *stepc, *hot_out; int32_t *act; float *reward, *obs; uint8_t *done; float4 *W, *X; uint32_t *wrow, *xrow;
   CHECK(hipMalloc(&hot, n * sizeof(u3))); CHECK(hipMalloc(&stepc, n * sizeof(u3))); CHECK(hipMalloc(&hot_out, n * sizeof(u3)));
   CHECK(hipMalloc(&act, n * 4)); CHECK(hipMalloc(&reward, n * 4)); CHECK(hipMalloc(&done, n));
-  CHECK(hipMalloc(&obs, n * 29 * 4)); CHECK(hipMalloc(&W, (size_t)S * 256)); CHECK(hipMalloc(&X, (size_t)R * 128 * 153));
+#ifdef PROBE_UC_OBS  // what-if: the observation buffer in memory the L2 does not allocate for (1 = fine-grained, 3 = uncached): the
+                     // 121 MB of rows per launch would stop evicting the table lines the gathers want to find in L2
+  CHECK(hipExtMallocWithFlags((void **)&obs, n * 29 * 4, PROBE_UC_OBS));
+#else
+  CHECK(hipMalloc(&obs, n * 29 * 4));
+#endif
+  CHECK(hipMalloc(&W, (size_t)S * 256)); CHECK(hipMalloc(&X, (size_t)R * 128 * 153));
   CHECK(hipMalloc(&wrow, n * 4)); CHECK(hipMalloc(&xrow, n * 4));
   CHECK(hipMemset(hot, 0, n * sizeof(u3))); CHECK(hipMemset(stepc, 0, n * sizeof(u3))); CHECK(hipMemset(act, 0, n * 4));
   CHECK(hipMemset(W, 0, (size_t)S * 256)); CHECK(hipMemset(X, 0, (size_t)R * 128 * 153));
