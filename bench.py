@@ -70,7 +70,9 @@ def parse(argv=None):
     p.add_argument("--steps", type=int, default=1530, help="timed steps (default: 10 episodes, SURVEY §8d)")
     p.add_argument("--warmup", type=int, default=153, help="untimed steps (default: 1 episode)")
     p.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                   help="default: configs2 on one GPU (the config the >= 10 M target is quoted on), configs4 on several")
+                   help="default: configs2 per GPU for every N (the config the >= 10 M target is quoted on: one workload for "
+                        "the whole 1/2/4/8-GPU curve); with N > 1 the line also carries BASELINE configs[4] "
+                        "(nn_full_medicare_all shape, 1 048 576 envs per GPU) measured in the same job: `configs4_sharded`")
     p.add_argument("--num-envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
     p.add_argument("--no-obs", action="store_true", help="reward-only step variant")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,6 +80,9 @@ def parse(argv=None):
                    help="skip the reported extras (always-alert policy, sorted episode order, posterior-mean reward)")
     p.add_argument("--no-parity", action="store_true",
                    help="skip the oracle replay of a strided sample of the timed batch that follows the timed region")
+    p.add_argument("--only-extras", default=None, metavar="NAME[,NAME...]",
+                   help="single-GPU run: of the reported extras only these (always_alert, sorted, posterior_mean, rollout, "
+                        "configs4, configs1)")
     p.add_argument("--no-calibration", action="store_true",
                    help="skip the in-process copy-rate / access-pattern probe that follows the timed region")
     p.add_argument("--seed", type=int, default=0)
@@ -98,8 +103,8 @@ def parse(argv=None):
                    help="scaling sweep in one command, e.g. --sweep 1,2,4,8: this process (which never touches a GPU) runs "
                         "`bench.py --gpus N` for every N in turn, each as a fresh group of child processes, and prints ONE "
                         "JSON line per N (value, per-GPU value, the job's own single-GPU reference, efficiency, what the "
-                        "collective costs, ranks seen) plus a closing summary line. Default workload: configs4 for every N, "
-                        "N = 1 included, so that all lines share one workload; --scaling weak (default) or strong")
+                        "collective costs, ranks seen) plus a closing summary line. Every job runs the default workload (configs2 "
+                        "per GPU, + configs4_sharded for N > 1) unless --workload says otherwise; --scaling weak (default) or strong")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the multi-rank path (ranks share the GPUs there are; with the "
                         "launcher_stub workload it needs no GPU at all)")
@@ -111,10 +116,8 @@ def parse(argv=None):
             p.error("--sweep takes a comma-separated list of GPU counts, e.g. 1,2,4,8")
         if not a.sweep or min(a.sweep) < 1:
             p.error("--sweep needs positive GPU counts")
-        if a.workload is None:
-            a.workload = "configs4"
     if a.workload is None:
-        a.workload = "configs2" if a.gpus == 1 else "configs4"
+        a.workload = "configs2"  # for every N: the driver computes scaling efficiency from the per-N values of ONE command
     return a
 
 
@@ -209,7 +212,7 @@ def run_sweep(args) -> int:
     for n in args.sweep:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--workload", args.workload, "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--scaling", args.scaling, "--backend", args.backend, "--seed", str(args.seed),
-               "--launch-timeout", str(args.launch_timeout), "--no-extras", "--no-cpu-baseline"]
+               "--launch-timeout", str(args.launch_timeout), "--no-cpu-baseline"] + ([] if n > 1 else ["--only-extras", "configs4"])
         if args.num_envs:
             cmd += ["--num-envs", str(args.num_envs)]
         if args.no_obs:
@@ -230,7 +233,9 @@ def run_sweep(args) -> int:
             line = {"sweep_n": n, "error": f"bench.py --gpus {n} exited with code {rc}", "stderr_tail": err[-1500:]}
         else:
             d = json.loads(js[-1])
+            c4 = d.get("configs4_sharded") or d.get("configs4_single_gpu") or {}
             line = {"sweep_n": n, **{k: d.get(k) for k in keep}, "workload": (d.get("config") or {}).get("workload"),
+                    "configs4_value": c4.get("value"), "configs4_kernel_us": c4.get("kernel_us"),
                     "num_envs_per_gpu": (d.get("config") or {}).get("num_envs_per_gpu"),
                     "parity_ok": (d.get("parity") or {}).get("ok"), "job_wall_s": round(time.time() - t0, 1)}
         lines.append(line)
@@ -244,6 +249,11 @@ def run_sweep(args) -> int:
         summary["efficiency_vs_smallest_n"] = {
             str(ln["sweep_n"]): ln["value"] / (base["value"] * ln["sweep_n"] / base["sweep_n"]) for ln in good}
         summary["baseline_n"] = base["sweep_n"]
+        c4 = [ln for ln in good if ln.get("configs4_value")]
+        if c4:  # BASELINE configs[4] (nn_full_medicare_all shape), measured inside every job of the sweep
+            b4 = min(c4, key=lambda ln: ln["sweep_n"])
+            summary["configs4_efficiency_vs_smallest_n"] = {
+                str(ln["sweep_n"]): ln["configs4_value"] / (b4["configs4_value"] * ln["sweep_n"] / b4["sweep_n"]) for ln in c4}
     print(json.dumps(summary), flush=True)
     return rc_all
 
@@ -511,6 +521,66 @@ def box_calibration(env, dt, ct, packed, torch):
     except Exception as e:  # noqa: BLE001  (a reported calibration, never fatal)
         out["error"] = repr(e)
     return out
+
+
+def sharded_workload(wl, args, rank, world, device, torch, HeatAlertVecEnv, synth, tables, wdist):
+    """One more workload of this very job, sharded like the headline (N > 1): BASELINE configs[4] = nn_full_medicare_all
+    shape, 1 048 576 envs per GPU, global env ids rank * n ..., the return all-gather once per episode -- W warm-up steps,
+    then exactly K steps between barrier + device synchronisation on both sides, MAX over ranks. Returns rank 0's dict."""
+    wname, n_default, augment, desc = WORKLOADS[wl]
+    n = args.num_envs or n_default
+    if args.scaling == "strong":
+        start, stop = wdist.shard_range(n, rank, world)
+        if (stop - start) * world != n:
+            return {"skipped": f"{n} envs do not divide by {world} ranks"}
+        n = stop - start
+    sd = synth.make_synth(wname, years=list(range(2006, 2017)), n_samples=100, seed=args.seed, extra_confounder_fips=60)
+    ct = tables.compile_from_synth(sd)
+    env = HeatAlertVecEnv(n, tables=tables.DeviceTables(ct, device), device=device, similar_climate_counties=augment,
+                          env_gid0=rank * n, write_obs=not args.no_obs)
+    gather = wdist.ReturnGatherer(n, device)
+    g = torch.Generator(device=device).manual_seed(4321 + rank)
+    pool = [(torch.rand(n, device=device, generator=g) < 0.1).to(torch.int32) for _ in range(16)]
+    env.reset(seed=args.seed)
+    T, stepno = ct.T, 0
+
+    def one():
+        nonlocal stepno
+        env.step(pool[stepno & 15])
+        stepno += 1
+        if stepno % T == 0:
+            gather.gather(env._final_return, async_op=True)
+
+    for _ in range(args.warmup):
+        one()
+    gather.wait()
+    wdist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        one()
+    gather.wait()
+    e1.record()
+    torch.cuda.synchronize()
+    wdist.barrier()
+    wall = wdist.max_over_ranks(time.perf_counter() - t0, device)
+    status = env.check_status()
+    packed = env.packed_state
+    mean_ret = float(gather.mean(env._final_return).item())
+    env.close()
+    total = float(n) * world * args.steps
+    cb = compulsory_bytes(ct.n_obs, not args.no_obs, packed)
+    return {"workload": desc, "value": total / wall, "unit": "env-steps/s", "per_gpu_value": total / wall / world,
+            "num_envs_per_gpu": n, "num_envs_total": n * world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "device_ms_per_step_rank0": e0.elapsed_time(e1) / args.steps,
+            "packed_lockstep_state": packed, "compulsory_bytes_per_env_step": cb["total"], "status_bits": status,
+            "mean_final_return": mean_ret,
+            "collective": "all_gather_into_tensor(f32[num_envs_per_gpu]) per episode, overlapped with the next episode's steps",
+            "note": "BASELINE configs[4] inside the same job as the headline (which keeps configs[2] per GPU for every N, so "
+                    "that one command gives the 1/2/4/8 curve on one workload); its one-GPU figure is `configs4_single_gpu` "
+                    "of the N = 1 line"}
 
 
 # ------------------------------------------------------------------------------------------ parity of the timed batch
@@ -864,13 +934,19 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
         e2.close()
         out["configs1_single_gpu"] = res
 
-    guarded("always_alert_policy", always_alert)
-    guarded("sorted_episode_order", sorted_order)
-    guarded("posterior_mean_reward", posterior_mean)
-    guarded("on_device_rollout", rollout)
-    if args.workload == "configs2":
+    only = None if not args.only_extras else set(args.only_extras.split(","))
+    want = lambda name: only is None or name in only  # noqa: E731
+    if want("always_alert"):
+        guarded("always_alert_policy", always_alert)
+    if want("sorted"):
+        guarded("sorted_episode_order", sorted_order)
+    if want("posterior_mean"):
+        guarded("posterior_mean_reward", posterior_mean)
+    if want("rollout"):
+        guarded("on_device_rollout", rollout)
+    if args.workload == "configs2" and want("configs4"):
         guarded("configs4_single_gpu", configs4)
-    if args.workload != "configs1":
+    if args.workload != "configs1" and want("configs1"):
         guarded("configs1_single_gpu", configs1)
 
 
@@ -1118,6 +1194,14 @@ def main():
             parity = parity_check(env, sd, ct, pool, act_log, torch)
         except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
             parity = {"error": repr(e), "ok": False}
+    # ---- N > 1: BASELINE configs[4] in the same job (every rank takes part; rank 0 reports)
+    c4_sharded = None
+    if world > 1 and args.workload == "configs2" and graph is None and not args.no_extras:
+        env.close()
+        try:
+            c4_sharded = sharded_workload("configs4", args, rank, world, device, torch, HeatAlertVecEnv, synth, tables, wdist)
+        except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
+            c4_sharded = {"error": repr(e)}
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
@@ -1221,6 +1305,8 @@ def main():
             "status_bits": status, "mean_final_return": mean_ret, "setup_s": t_setup,
             "parity": parity,
         }
+        if c4_sharded is not None:
+            out["configs4_sharded"] = c4_sharded
         if world == 1 and args.episode_order == "iid" and not args.graph and not args.no_extras:
             env.close()
             extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, augment, pool, cb, T, wname)

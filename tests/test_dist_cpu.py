@@ -196,8 +196,10 @@ def test_bench_defaults_follow_baseline_configs():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.parse([]).workload == "configs2" and b.parse(["--gpus", "8"]).workload == "configs4"
-    assert b.parse(["--sweep", "1,2,4,8"]).workload == "configs4" and b.parse(["--sweep", "1,8"]).sweep == [1, 8]
+    # one workload for every N: the driver computes scaling efficiency from the per-N values of one command; BASELINE
+    # configs[4] rides along in the N > 1 jobs as `configs4_sharded`
+    assert b.parse([]).workload == "configs2" and b.parse(["--gpus", "8"]).workload == "configs2"
+    assert b.parse(["--sweep", "1,2,4,8"]).workload == "configs2" and b.parse(["--sweep", "1,8"]).sweep == [1, 8]
     assert b.WORKLOADS["configs4"][:3] == ("nn_full_medicare_all", 1048576, False)
     cb = b.compulsory_bytes(29, True)
     assert cb["total"] == 161 and b.compulsory_bytes(29, False)["total"] == 45
