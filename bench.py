@@ -623,15 +623,24 @@ def parity_check(env, sd, ct, pool, act_log, torch, extra_steps=8, max_sample=40
     # ---- episode tuples: the restated device RNG, with the sticky-budget chain from episode 0 (env.py:167-170, Q9)
     tuples = {}
     if env.episode_order == "iid":
-        sticky = np.full(len(idx), -1, np.int64)
-        for ep in range(e_cur + 1):
-            cw, yi, cc, sm, b, sticky = SM.draw_episodes(ct, env._reset_cfg, env.env_gid0 + idx, np.full(len(idx), ep), sticky,
-                                                         "augment" in env.fixes)
-            if ep >= e_cur - 1:
-                tuples[ep] = (cw, yi, cc, sm, b)
+        def chain(sticky0):
+            sticky, got = sticky0.copy(), {}
+            for ep in range(e_cur + 1):
+                cw, yi, cc, sm, b, sticky = SM.draw_episodes(ct, env._reset_cfg, env.env_gid0 + idx, np.full(len(idx), ep), sticky,
+                                                             "augment" in env.fixes)
+                if ep >= e_cur - 1:
+                    got[ep] = (cw, yi, cc, sm, b)
+            return got
+
+        tuples = chain(np.full(len(idx), -1, np.int64))
+        out["tuples"] = "restated device RNG, sticky-budget chain from episode 0"
+        if not np.array_equal(tuples[e_cur][4], st["budget"]) and env._reset_cfg[4] == 0:
+            # a budget sticks to an env for good (env.py:167-170, Q9): on an env that had been reset before this seed (the
+            # multi-GPU flow re-seeds after rank 0's solo run) the chain starts from the budgets that stuck back then
+            tuples = chain(st["sticky_budget"].astype(np.int64))
+            out["tuples"] = "restated device RNG; budgets = the sticky budgets the envs carried into this seed (Q9)"
         for name, want in zip(("county_w", "year_i", "coef_col", "sample", "budget"), tuples[e_cur]):
             same(f"episode tuple ({name})", st[name], want)
-        out["tuples"] = "restated device RNG, sticky-budget chain from episode 0"
     else:  # episode_order='sorted' relabels envs after every reset: the tuples are taken from the state itself
         tuples[e_cur] = tuple(st[k].astype(np.int64) for k in ("county_w", "year_i", "coef_col", "sample", "budget"))
         out["tuples"] = "read back from the env (sorted order relabels env indices)"
