@@ -90,7 +90,7 @@ MUTANTS = [
     ("a restore keeps the row counts", "  b.hist_valid = 0;\n  b.poisoned = 0;", "  b.poisoned = 0;"),
     ("a restored buffer is taken to be still poisoned (round 5, GPU fuzz seed 505 sequence 357)",
      "  b.poisoned = 0;  // the caller's copy covered the mirror's day words too", "  //"),
-    ("another order workspace inherits the row counts", "{ b.has_order_ws = 1; b.hist_valid = 0; }", "{ b.has_order_ws = 1; }"),
+    ("another order workspace inherits the row counts", "  b.has_order_ws = 1; b.hist_valid = 0;\n", "  b.has_order_ws = 1;\n"),
     ("a failed launch after a conversion forgets that the mirror was rewritten",
      "  if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }", "  if (p.converted == 1) { b.pk_valid = 1; }"),
 ]

@@ -288,7 +288,11 @@ static inline void bk_sort(W2aBook &b, Dev &d) {
   b.hist_valid = 0;  // ... and so are the per-env ranks inside the feature rows
 }
 static inline void bk_grouped(W2aBook &b) { b.perm_valid = b.graph_autoreset ? 0 : 1; }
-static inline void bk_order_attach(W2aBook &b) { b.has_order_ws = 1; b.hist_valid = 0; }
+// w2a_rollout_order_attach with ANOTHER workspace: it holds neither row counts nor (drops_order) a visiting order yet
+static inline void bk_order_attach(W2aBook &b, bool drops_order = false) {
+  b.has_order_ws = 1; b.hist_valid = 0;
+  if (drops_order) { b.has_order = 0; b.rm_valid = 0; }
+}
 static inline void bk_order_set(W2aBook &b) { b.has_order = 1; b.rm_valid = 0; }
 static inline void bk_rm_prepared(W2aBook &b) { b.rm_valid = b.graph_autoreset ? 0 : 1; }
 

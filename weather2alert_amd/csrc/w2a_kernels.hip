@@ -582,8 +582,9 @@ static int order_attach(w2a_env *env, void *workspace, size_t workspace_bytes, c
   env->order_tile_start = (uint32_t *)p;
   env->order_ws = workspace;
   // the order of an earlier workspace stays a valid permutation; this one holds none yet
-  if (env->order && env->order != order) { env->order = nullptr; env->bk.has_order = 0; env->bk.rm_valid = 0; }
-  bk_order_attach(env->bk);
+  const bool drops = env->order && env->order != order;
+  if (drops) env->order = nullptr;
+  bk_order_attach(env->bk, drops);
   return W2A_OK;
 }
 
