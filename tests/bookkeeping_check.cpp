@@ -235,10 +235,17 @@ static void check_invariants(World &w) {
 // ---------------------------------------------------------------- entry points (bookkeeping side of w2a_kernels.hip)
 static void end_call(World &w) { StubDev d{w}; bk_end_call(w.bk, d); }
 
-static void api_reset_device(World &w, const Cfg &c, bool masked, unsigned sel) {  // w2a_reset_device_rng + launch_reset
+static void api_reset_device(World &w, const Cfg &c, bool masked, unsigned sel, bool launch_fails = false) {  // w2a_reset_device_rng + launch_reset
   bk_note_budgets(w.bk, c.budget_kw >= 0 ? c.budget_kw : w.bk.b0_max, c.mode == 2, c.sticky != 0);
   StubDev d{w};
+  const W2aBook before = w.bk;
   bk_reset(w.bk, d, false, masked);
+  if (launch_fails) {  // (the budget note above stays: conservative)
+    bk_reset_rollback(w.bk, before, false, masked);
+    note(w, "    (the launch failed: rolled back)");
+    end_call(w);
+    return;
+  }
   if (masked) read_canon(w, "k_reset (masked)");
   for (int i = 0; i < w.ne; ++i)
     if (!masked || ((sel >> i) & 1u)) new_episode(w, i, c);
@@ -277,10 +284,12 @@ static void api_reset_tuples(World &w, bool with_budgets, int64_t bmax, bool mas
     if (!w.bfs) w.trace.push_back("    w2a_set_budget_bound(" + std::to_string(seen) + ")");
   }
 }
-static void api_observe(World &w) {  // w2a_observe
+static void api_observe(World &w, bool launch_fails = false) {  // w2a_observe
   StubDev d{w};
+  const W2aBook before = w.bk;
   bk_reset(w.bk, d, true, false);
-  read_canon(w, "k_reset (observe)");
+  if (launch_fails) bk_reset_rollback(w.bk, before, true, false);
+  else read_canon(w, "k_reset (observe)");
   end_call(w);
 }
 static void api_set_autoreset(World &w, const Cfg &c) {  // w2a_set_autoreset
@@ -466,8 +475,8 @@ static std::string describe(const Op &o) {
   switch (o.kind) {
     case OP_STEP: snprintf(b, sizeof b, "step(wide %d autoreset %d next %d given %d unpacked %d%s%s)", o.wide, o.autoreset, o.next, o.given,
                            o.unpacked, o.capturing ? " CAPTURING" : "", o.fails ? " LAUNCH FAILS" : ""); break;
-    case OP_RESET_DEVICE: snprintf(b, sizeof b, "reset_device(kw %lld mode %d sticky %d masked %d sel %u)", (long long)o.cfg.budget_kw,
-                                   o.cfg.mode, o.cfg.sticky, o.masked, o.sel); break;
+    case OP_RESET_DEVICE: snprintf(b, sizeof b, "reset_device(kw %lld mode %d sticky %d masked %d sel %u%s)", (long long)o.cfg.budget_kw,
+                                   o.cfg.mode, o.cfg.sticky, o.masked, o.sel, o.fails ? " LAUNCH FAILS" : ""); break;
     case OP_RESET_TUPLES: snprintf(b, sizeof b, "reset_tuples(budgets %d max %lld masked %d sel %u tell %d)", o.with_budgets,
                                    (long long)o.bmax, o.masked, o.sel, o.tell); break;
     case OP_ROLLOUT: snprintf(b, sizeof b, "rollout(%d, fixes %d, prep %d)", o.n_steps, o.fixes, o.prep); break;
@@ -475,7 +484,7 @@ static std::string describe(const Op &o) {
     case OP_SORT: return "sort";
     case OP_GROUP: return "group_by_column";
     case OP_PM_REWARD: return "posterior_mean_reward";
-    case OP_OBSERVE: return "observe";
+    case OP_OBSERVE: return o.fails ? "observe LAUNCH FAILS" : "observe";
     case OP_INVALIDATE: snprintf(b, sizeof b, "checkpoint restore (shape %d); invalidate%s", o.shape, o.tell ? "; set_budget_bound" : ""); break;
     case OP_REPLAY: snprintf(b, sizeof b, "graph replay (kind %d)", o.graph); break;
     case OP_SET_AUTORESET: snprintf(b, sizeof b, "set_autoreset(kw %lld mode %d sticky %d)", (long long)o.cfg.budget_kw, o.cfg.mode, o.cfg.sticky); break;
@@ -495,7 +504,7 @@ static void apply(World &w, const Op &o) {
       if (o.given) api_pm_reward(w);
       api_step(w, o.wide, o.autoreset && w.has_autoreset, o.next, o.given, o.unpacked, o.capturing, o.fails);
       break;
-    case OP_RESET_DEVICE: api_reset_device(w, o.cfg, o.masked, o.sel); api_set_autoreset(w, o.cfg); break;
+    case OP_RESET_DEVICE: api_reset_device(w, o.cfg, o.masked, o.sel, o.fails); if (!o.fails) api_set_autoreset(w, o.cfg); break;
     case OP_RESET_TUPLES: api_reset_tuples(w, o.with_budgets, o.bmax, o.masked, o.sel, o.tell); break;
     case OP_ROLLOUT:
       if (o.prep >= 1) { api_rollout_order(w); if (o.prep >= 2) api_rm_prepare(w); }
@@ -505,7 +514,7 @@ static void apply(World &w, const Op &o) {
     case OP_SORT: api_sort(w); break;
     case OP_GROUP: api_group(w); break;
     case OP_PM_REWARD: api_pm_reward(w); break;
-    case OP_OBSERVE: api_observe(w); break;
+    case OP_OBSERVE: api_observe(w, o.fails); break;
     case OP_INVALIDATE: api_invalidate(w, o.tell, o.shape); break;
     case OP_REPLAY: if (w.graphs & o.graph) api_graph_replay(w, o.graph); break;
     case OP_SET_AUTORESET: api_set_autoreset(w, o.cfg); break;
@@ -555,7 +564,7 @@ static void run_sequence(uint64_t seed, int n_ops) {
       o.wide = o.given || rng.coin(70); o.unpacked = rng.coin(10); o.fails = rng.coin(3);
     } else if (u < 48) {
       o.kind = OP_RESET_DEVICE; o.cfg = random_cfg(rng); o.masked = rng.coin(40);
-      o.sel = rng.coin(20) ? all : (unsigned)rng.below(all + 1);
+      o.sel = rng.coin(20) ? all : (unsigned)rng.below(all + 1); o.fails = rng.coin(4);
     } else if (u < 54) {
       o.kind = OP_RESET_TUPLES; o.with_budgets = rng.coin(70); o.masked = rng.coin(40); o.tell = rng.coin(80);
       o.bmax = rng.coin(80) ? 9 : 90000; o.sel = (unsigned)rng.below(all + 1);
@@ -566,7 +575,7 @@ static void run_sequence(uint64_t seed, int n_ops) {
     else if (u < 73) o.kind = OP_SORT;
     else if (u < 78) o.kind = OP_GROUP;
     else if (u < 83) o.kind = OP_PM_REWARD;
-    else if (u < 86) o.kind = OP_OBSERVE;
+    else if (u < 86) { o.kind = OP_OBSERVE; o.fails = rng.coin(10); }
     else if (u < 89) { o.kind = OP_INVALIDATE; o.tell = rng.coin(70); }
     else if (u < 93) {
       o.kind = OP_STEP; o.capturing = true;
@@ -636,7 +645,9 @@ static std::vector<Op> all_ops(int walk) {
     for (int m = 0; m < 3; ++m) {  // unmasked; a mask selecting env 0; a mask selecting both (the handle cannot see what a mask selects)
       Op o; o.kind = OP_RESET_DEVICE; o.cfg = c; o.masked = m > 0; o.sel = m == 1 ? 1u : 3u;
       v.push_back(o);
+      if (walk == 1) { o.fails = true; v.push_back(o); }  // ... and the same reset with a k_reset launch that fails
     }
+  if (walk == 1) { Op o; o.kind = OP_OBSERVE; o.fails = true; v.push_back(o); }
   for (int wb = 0; wb < 2; ++wb)
     for (int64_t bmax : {(int64_t)9, (int64_t)90000})
       for (int m = 0; m < 3; ++m)

@@ -91,6 +91,8 @@ MUTANTS = [
     ("a restored buffer is taken to be still poisoned (round 5, GPU fuzz seed 505 sequence 357)",
      "  b.poisoned = 0;  // the caller's copy covered the mirror's day words too", "  //"),
     ("another order workspace inherits the row counts", "  b.has_order_ws = 1; b.hist_valid = 0;\n", "  b.has_order_ws = 1;\n"),
+    ("a failed full reset claims the canonical words it never wrote",
+     "  const bool unpacked = (masked || observe_only) && !before.canon_valid;", "  const bool unpacked = !before.canon_valid;"),
     ("a failed launch after a conversion forgets that the mirror was rewritten",
      "  if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }", "  if (p.converted == 1) { b.pk_valid = 1; }"),
 ]

@@ -189,6 +189,15 @@ static inline void bk_reset(W2aBook &b, Dev &d, bool observe_only, bool masked) 
   b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;
 }
 
+// The k_reset launch bk_reset prepared did not happen: the state is what it was, except that the conversion a masked
+// reset / w2a_observe on the packed form asked for did run and left both forms current. Derived structures are dropped.
+static inline void bk_reset_rollback(W2aBook &b, const W2aBook &before, bool observe_only, bool masked) {
+  const bool unpacked = (masked || observe_only) && !before.canon_valid;
+  b = before;
+  if (unpacked) b.canon_valid = 1;
+  b.hist_valid = 0; b.perm_valid = 0; b.rm_valid = 0;
+}
+
 struct BkStepPlan {
   int kernel;            // W2A_BK_STEP_*; < 0: refused (the capture would have to record a conversion of the state's form)
   int32_t uni_nd;        // kernel argument of the packed variant (a table constant; the day is read on the device)

@@ -299,10 +299,7 @@ static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   if (e != hipSuccess) {
     // the reset did not happen: the state is what it was, except that a conversion bk_reset asked for (a masked reset or
     // w2a_observe on the packed form) did run and left both forms current; derived structures are dropped (conservative)
-    const bool unpacked = !before.canon_valid && env->bk.canon_valid;
-    env->bk = before;
-    if (unpacked) env->bk.canon_valid = 1;
-    env->bk.hist_valid = 0; env->bk.perm_valid = 0; env->bk.rm_valid = 0;
+    bk_reset_rollback(env->bk, before, a.from_tuples == 2, a.mask != nullptr);
     end_call(env, (hipStream_t)stream);
     return fail(W2A_ERR_HIP, "reset: launch failed: %s", hipGetErrorString(e));
   }
