@@ -479,7 +479,7 @@ def test_next_step_autoreset_in_kernel(dev, n, fixes):
 
 def test_packed_lockstep_state_equals_canonical_state(dev):
     """While a batch is in lock step the 64-envs-per-wave kernel streams a 16-B packed mirror of the per-env state
-    (day / episode length / finished bit as kernel arguments) instead of the 24-B canonical words. Same arithmetic, so
+    (the day in one word per 64-env tile, the episode length as a kernel argument) instead of the 24-B canonical words. Same arithmetic, so
     everything must be BIT-identical to the unpacked kernel: observations, rewards, done, returns, decoded state --
     through a whole episode, the host-driven lock-step autoreset into the next one, state() read-backs (packed ->
     canonical conversion mid-episode), a rollout() in between (leaves lock step: canonical form until the next reset),

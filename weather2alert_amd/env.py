@@ -81,8 +81,13 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          length and the whole batch resets together, so the host counts steps and launches the
                          reset kernel after the terminal step (the step kernel then runs its leaner, full-occupancy
                          variant). False: each env restarts inside the step kernel whenever it finishes (needed
-                         after partial resets). None (default): True when the tables allow it; falls back to
+                         after partial resets, and what a loop recorded into a hipGraph needs: no reset can be
+                         launched between two recorded steps; a batch that is in lock step anyway keeps the packed
+                         16-B state there too). None (default): True when the tables allow it; falls back to
                          False by itself after a masked reset.
+                         hipGraphs: step() neither synchronises nor allocates and reads the day from device memory;
+                         step once eagerly, then capture (torch.cuda.graph). The library keeps the form of the state the
+                         recorded steps work on current from then on (include/w2a.h, w2a_state_bytes).
     faithful / fixes     faithful=True (default) reproduces every reference quirk -- all parity
                          claims refer to this mode. ``fixes`` opts into individual corrections (faithful=False =
                          all of them): "alert_2wks" (Q1: the agent's 14-day count feeds the reward), "lag" (Q3:
