@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Static instruction budget of one kernel of libw2a.so from its gfx950 ISA (hipcc -S; cross-compiles, no GPU needed):
 instructions per basic block, classified as the SQ counters classify them (MFMA / transcendental / other VALU / LDS /
-VMEM / SALU+SMEM), with the loop nesting taken from the backward branches. With --tiles the per-launch totals of
-k_posterior_mean_i8 are predicted from the workload's tile counts and compared with the rocprofv3 --pmc figures
-(SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_INSTS_LDS, SQ_VALU_MFMA_BUSY_CYCLES) of profiles/ -- DESIGN.md §5.
+VMEM / SALU+SMEM), with the loop nesting taken from the backward branches. The per-launch totals of
+k_posterior_mean_i8 follow from these counts and the workload's tile counts (waves x set-up + tile-heads x loop body) and
+are compared in DESIGN.md §5 with the rocprofv3 --pmc figures of profiles/r05/pmc_configs2_pm_matrix_i8.json
+(SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES) -- VERDICT r4 item 6.
 
 usage: python tools/isa_budget.py [--kernel k_posterior_mean_i8] [--asm /tmp/w2a_dev.s]"""
 import argparse
@@ -82,7 +83,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="k_posterior_mean_i8")
     ap.add_argument("--asm", default=None)
-    ap.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "r05", "pmc_configs2_pm_matrix_i8.json"))
     a = ap.parse_args()
     if a.asm is None:
         a.asm = "/tmp/_w2a_dev.s"
