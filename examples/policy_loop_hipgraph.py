@@ -22,14 +22,14 @@ n, G = 262144, 51                      # 51 recorded days: three replays = one 1
 envs = HeatAlertVecEnv(n, tables=tables, similar_climate_counties=True, lockstep=False)  # restarts inside the step kernel
 obs, _ = envs.reset(seed=0)
 dev = obs.device
-w = torch.zeros(obs.shape[1], device=dev)
-w[envs.feature_names.index("heat_qi")] = 8.0          # a one-layer "policy": alert when heat_qi is high
-actions = torch.zeros(n, dtype=torch.uint8, device=dev)
+heat = obs[:, envs.feature_names.index("heat_qi")]     # a view of the env's own observation buffer (rewritten by step())
+left = obs[:, envs.feature_names.index("remaining_budget")]
+actions = torch.zeros(n, dtype=torch.bool, device=dev)
 total = torch.zeros(n, device=dev)
 
 
 def one_day():
-    torch.gt(obs @ w, 7.4, out=actions.view(torch.bool))  # obs is the env's own buffer: rewritten in place by step()
+    torch.logical_and(heat > 0.92, left > 0, out=actions)  # the "policy": alert on hot days while budget is left
     _, reward, _, _, _ = envs.step(actions)
     total.add_(reward)
 
