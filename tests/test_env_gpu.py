@@ -1585,6 +1585,55 @@ def test_packed_state_at_the_limits_of_its_bit_fields(dev):
     B.close()
 
 
+def test_bench_parity_block_passes_and_can_fail(dev):
+    """bench.py's `parity` block (the oracle replay of a strided sample of the batch that was just timed) on a small batch:
+    green after two and a half episodes of step() -- and red, naming what differs, when the finished episodes' returns,
+    one env's integer state or one observation row are tampered with. A parity bit that cannot fail proves nothing."""
+    import importlib.util
+
+    from weather2alert_amd import HeatAlertVecEnv
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sd = synth.make_synth("linear", n_fips=30, years=[2006, 2007, 2008], n_samples=7, n_days=20, seed=8, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    n = 5000
+    g = torch.Generator(device=dev).manual_seed(77)
+    pool = [(torch.rand(n, device=dev, generator=g) < 0.25).to(torch.int32) for _ in range(16)]
+
+    def run(tamper=None):
+        env = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True)
+        env.reset(seed=4)
+        log = []
+        for s in range(2 * 20 + 9):
+            env.step(pool[s & 15])
+            log.append(s & 15)
+        if tamper == "return":
+            env._final_return[n - 1] += 0.01
+        elif tamper == "obs":
+            env._obs[0, 3] += 1.0
+        elif tamper == "state":  # one more alert on env 0's books: a single bit of its packed counters
+            st = env.state_dict()
+            w = st["state"].view(torch.int32)
+            hot3 = (256 + ((16 * n + 255) // 256) * 256) // 4  # header, then `cold`; hot3 follows (w2a_state_bytes)
+            w[hot3] += 1 << 10  # dyn0: used[10:20)
+            env.load_state_dict(st)
+        out = bench.parity_check(env, sd, ct, pool, log, torch, extra_steps=5, max_sample=256)
+        env.close()
+        return out
+
+    ok = run()
+    assert ok["ok"] and ok["ints_exact"] and ok["obs_exact"] and ok["max_abs_reward_err"] <= 1e-5, ok
+    assert ok["episodes_replayed"] == [1, 2] and ok["env_steps_replayed_per_env"] == 20 + 9 + 5 and ok["sampled"] >= 256
+    bad = run("return")
+    assert not bad["ok"] and bad["return_err_over_tolerance"] > 1.0, bad
+    bad = run("obs")
+    assert not bad["ok"] and bad["obs_exact"] is False, bad
+    bad = run("state")
+    assert not bad["ok"] and not bad["ints_exact"] and any("used" in x or "remaining" in x for x in bad["notes"]), bad
+
+
 def test_other_schema_parity(dev):
     """A schema with one exogenous feature fewer (n_obs = 28): kernels, observation order and rewards still
     match the oracle, which derives everything from the column / key names as well."""
