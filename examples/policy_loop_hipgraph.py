@@ -34,21 +34,16 @@ def one_day():
     total.add_(reward)
 
 
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    one_day()                           # warm-up outside the capture (also puts the batch on its packed form)
-torch.cuda.current_stream().wait_stream(side)
-graph = torch.cuda.CUDAGraph()
-with torch.cuda.graph(graph):
-    for _ in range(G):
-        one_day()
+# one eager warm-up day (it also puts the batch on its packed form), then the capture; .replay() reads the env's status
+# word behind every replay, so a block that could not run (W2A_ST_STALE_GRAPH) raises instead of going unnoticed
+block = envs.record_steps(one_day, G)
 print("recorded", G, "days; step kernel:", envs.last_step_kernel, "| packed state:", envs.packed_state)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 replays = 30
 for _ in range(replays):
-    graph.replay()
+    block.replay()
+block.finish()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 st = envs.state()

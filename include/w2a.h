@@ -10,10 +10,13 @@
  *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch) unless marked host.
  *     The library allocates nothing on the device and frees nothing but the handle.
  *   - All calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- *     default stream). Three calls wait for the device: w2a_create (once per handle: it uploads the slot map and
- *     scans the tables on the NULL stream, then hipDeviceSynchronize), w2a_invalidate and w2a_read_status (both
- *     wait for `stream` only, to read a value back). Nothing else synchronises or allocates, so everything
- *     else may be recorded into a hipGraph (w2a_state_bytes below says what a recorded w2a_step implies).
+ *     default stream). Two calls wait for the device: w2a_create (once per handle: it uploads the slot map and
+ *     scans the tables on the NULL stream, then hipDeviceSynchronize) and w2a_read_status (waits for `stream`
+ *     only, to read the status word back). Nothing else synchronises or allocates. What may be RECORDED into a
+ *     hipGraph is w2a_step (w2a_state_bytes below says what a recording implies) and, while they need no
+ *     conversion of the state's form, w2a_posterior_mean_reward / w2a_policy_actions / w2a_get_state; every
+ *     other entry point that launches work fails with W2A_ERR_STATE while `stream` is capturing -- a replay
+ *     would run it without the handle's bookkeeping (episode boundaries inside a graph: W2A_STEP_AUTORESET).
  *   - Return value: 0 = W2A_OK, negative = error (w2a_last_error() gives the text). Nothing
  *     throws across the ABI. Arguments are validated on the host before any launch; values
  *     that live in device arrays (episode tuples, actions) are range-checked inside the
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define W2A_ABI_VERSION 17
+#define W2A_ABI_VERSION 18
 #define W2A_ROW_FLOATS 32 /* floats per feature / weight row: one 128-B line */
 
 enum {
@@ -47,8 +50,8 @@ enum {
   W2A_ST_BAD_ACTION = 2,  /* action not in {0,1} (reference action_space = Discrete(2), env.py:95) */
   W2A_ST_STEP_AFTER_DONE = 4, /* step() on a finished episode without autoreset */
   W2A_ST_STALE_GRAPH = 8  /* a replayed hipGraph holds a w2a_step on the packed lock-step form of the state, and that form
-                             could not be kept current (the batch left lock step, budgets went out of sight, a checkpoint
-                             was restored): the replayed step did NOTHING -- see w2a_state_bytes */
+                             could not be kept current (the batch left lock step: a masked reset, a restored
+                             checkpoint): the replayed step did NOTHING -- see w2a_state_bytes */
 };
 
 /* action buffer element types accepted by w2a_step */
@@ -72,6 +75,11 @@ enum {
                              AutoresetMode.NEXT_STEP): the terminal step leaves the env finished with its stale
                              observation; the next call ignores that env's action, draws its next episode and returns
                              the episode's first observation with reward 0 and done 0 */
+  W2A_STEP_NO_CAPTURE = 512, /* the caller drives episode boundaries from the host (it counts days and launches a reset
+                             after the terminal step): such a loop cannot be recorded into a hipGraph -- a replay would
+                             reset at a fixed position of the graph, or never -- so the call fails with W2A_ERR_STATE
+                             while `stream` is capturing instead of recording a step (no cost otherwise: the capture
+                             status is queried anyway) */
   W2A_STEP_SKIP_FINISHED = 64, /* with W2A_STEP_REWARD_GIVEN: envs whose episode is over are left untouched (reward
                              written as 0, done 1, state / return / observation unchanged, no status bit): policy
                              loops over batches that are not in lock step */
@@ -142,7 +150,8 @@ const char *w2a_last_error(void);
  * reset, one episode length for every (county, year), plain steps and rollouts since -- the day and the episode length
  * are the same for every env; the 64-envs-per-wave step kernel then streams 8 + 8 B of packed state per env in and 8 B
  * out instead of 12 + 12 and 12, with the day in the mirror's per-tile day word (needs T <= 255, S < 65536, n_samples
- * <= 1024, S_w * Y < 2^22 and budgets <= 65535; anything else uses the canonical arrays). The library converts between
+ * <= 1024, S_w * Y < 2^22 -- table properties; budgets may be anything: those the mirror's 16-bit field cannot hold are
+ * read from the canonical words inside the kernel; other tables use the canonical arrays). The library converts between
  * the two forms by itself whenever an entry point needs the other one; a caller that rewrites the state buffer behind
  * the library's back (checkpoint restore) must call w2a_invalidate.
  * Stream capture. Every step kernel reads the day from device memory, so a w2a_step recorded into a hipGraph steps
@@ -152,14 +161,17 @@ const char *w2a_last_error(void);
  * every call, so that a replay may come at any time:
  *   - recorded on the packed form (a lock-step batch of >= 131 072 envs, or W2A_STEP_WIDE, after one eager step): the
  *     mirror stays the primary form; calls that work on the canonical words (resets, rollouts, state reads) convert
- *     back before they return. Where the batch can no longer be packed (a masked reset, budgets handed over in device
- *     memory without w2a_set_budget_bound, w2a_invalidate) the mirror is marked stale on the device and a replay of the
- *     recorded step does nothing but raise W2A_ST_STALE_GRAPH -- until the next whole-batch reset makes it packable again.
+ *     back before they return. Where the batch can no longer be packed (a masked reset, w2a_invalidate) the mirror is
+ *     marked stale on the device and a replay of the recorded step does nothing but raise W2A_ST_STALE_GRAPH -- until
+ *     the next whole-batch reset (of any kind: device RNG or the caller's tuples, with or without budgets) makes it
+ *     packable again.
  *   - recorded on the canonical form: the handle never uses the packed form again.
  *   Replays advance days behind the host's back: a handle with a recorded step answers W2A_Q_LOCKSTEP_DAY with -1 (it
- *   still knows WHETHER the batch is in lock step, which is all the packed step and the matrix-core rollout need); after
- *   a recorded W2A_STEP_AUTORESET step, which re-draws episodes on replay, it no longer claims lock step, a valid column
- *   grouping (w2a_posterior_mean_reward) or a valid tile list (w2a_rollout_mfma_prepare) at all.
+ *   still knows WHETHER the batch is in lock step, which is all the packed step and the matrix-core rollout need).
+ *   Lock step survives a recorded W2A_STEP_AUTORESET step too (envs that are on one day finish, and restart, together:
+ *   W2A_Q_LOCKSTEP stays 1 and the batch stays on the packed form); what such a handle never again reports valid is
+ *   what belongs to particular EPISODES, which replays re-draw behind the host's back: the day, the column grouping
+ *   (w2a_posterior_mean_reward), the tile list (w2a_rollout_mfma_prepare), the row counts of the visiting order.
  * The decisions are plain C++ in csrc/w2a_bookkeeping.h (run on the CPU under sanitizers, randomly and exhaustively, by
  * tests/test_bookkeeping_cpu.py). */
 size_t w2a_state_bytes(int64_t num_envs);
@@ -341,7 +353,7 @@ int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream);
 
 /* What the handle knows (host-side bookkeeping, no device work): the day every env is on if the batch is known to be in
  * lock step AND the host can know the day (-1 otherwise: not in lock step, past the terminal step, or a step of this
- * handle was recorded into a hipGraph); whether tables and budgets allow the lock-step mirror at all; which of the two
+ * handle was recorded into a hipGraph); whether the tables allow the lock-step mirror at all; which of the two
  * forms of the step state is current; whether the batch is known to be in lock step. */
 enum { W2A_Q_LOCKSTEP = 6,           /* 1: every env is known to be on the same day of an episode of the one length there is */
        W2A_Q_LOCKSTEP_DAY = 0, W2A_Q_PACKED_ELIGIBLE = 1, W2A_Q_PACKED_CURRENT = 2, W2A_Q_CANONICAL_CURRENT = 3,
@@ -352,25 +364,13 @@ enum { W2A_Q_LOCKSTEP = 6,           /* 1: every env is known to be on the same 
 int w2a_query(w2a_env *env, int what);
 
 /* The caller has overwritten the state buffer (e.g. restored a checkpoint of its canonical part) on `stream`: forget
- * every derived form (lock-step mirror, column grouping, what is known about days and budgets). Waits for `stream` --
- * and for nothing else on the device -- while it scans the restored state for its largest budget, current and sticky,
- * so that nothing has to be stated afterwards (restored budgets below zero count as 0, as in the reset kernels).
- * Fails with W2A_ERR_STATE while `stream` is recording a hipGraph. If the scan itself fails (W2A_ERR_HIP) the handle is
- * still invalidated; budgets then stay unknown -- the packed form off -- until w2a_set_budget_bound. */
+ * every derived form (lock-step mirror, column grouping, row counts, what is known about days). Host-side bookkeeping
+ * only -- plus, on a handle with a recorded packed step, one small launch on `stream` that marks the mirror stale --:
+ * no wait, nothing read back. (Until ABI 17 the call scanned the restored buffer for its largest budget and waited for
+ * the stream, and w2a_set_budget_bound let a caller state one: the packed form held budgets in 16 bits and the handle had
+ * to bound them from the host side. The packed kernel now serves any budget; both are gone.)
+ * Fails with W2A_ERR_STATE while `stream` is recording a hipGraph. */
 int w2a_invalidate(w2a_env *env, void *stream);
-/* The library tracks an upper bound of every budget the state buffer holds -- the current episodes' and the sticky
- * ones later device-RNG resets hand out again (env.py:167-170) -- from the reset arguments (the packed lock-step form
- * holds budgets in 16 bits). Budgets handed over in DEVICE memory (w2a_reset with a budget array, a restored
- * checkpoint) are unknown to it and switch the packed form off; a caller that knows their maximum says so here
- * (bound < 0: unknown again).
- *   after w2a_reset:      `bound` covers the budgets just handed over; the library combines it with what it knew before
- *                         (sticky budgets of earlier episodes live on). If that was "no bound exists" -- a sticky
- *                         W2A_BUDGET_CENTERED budget is a random walk, also inside the kernels -- the statement changes
- *                         nothing: the unbounded values are still there as sticky budgets.
- *   after w2a_invalidate: nothing needs stating (the library has scanned the restored buffer, sticky budgets included); a
- *                         `bound` given anyway only ever raises what it found.
- * The parameters of w2a_set_autoreset keep counting on top of either (in-kernel autoresets go on drawing with them). */
-int w2a_set_budget_bound(w2a_env *env, int64_t bound);
 
 /* Synchronise `stream`, read and clear the device status word (host int out). */
 int w2a_read_status(w2a_env *env, int32_t *status_out, void *stream);

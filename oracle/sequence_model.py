@@ -28,7 +28,6 @@ _M64 = (1 << 64) - 1
 _PHI = np.uint64(0x9E3779B97F4A7C15)
 _C1 = np.uint64(0xBF58476D1CE4E5B9)
 _C2 = np.uint64(0x94D049BB133111EB)
-INF = 1 << 62
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 S64_MIN_ENVS = 131072
 FIX_BITS = ("alert_2wks", "lag", "penalty", "obs", "augment")  # the W2A_FIX_* bits; "budget" is the sticky=0 argument
@@ -98,7 +97,6 @@ class HandleModel:
         nd = np.unique(np.asarray(ct.n_days))
         self.uniform = len(nd) == 1 and nd[0] > 0
         self.uni_nd = int(nd[0]) if self.uniform else -1
-        self.b0_max = int(np.asarray(ct.B0).max())
         self.lockstep = bool(self.uniform and lockstep is not False)
         self.V.reset(*(np.zeros(self.n, np.int64) for _ in range(5)))  # five separate arrays: they are written in place
         self.V.n_days = np.ones(self.n, np.int64)          # k_init_state: n_days 1, finished
@@ -116,9 +114,7 @@ class HandleModel:
         # ---- mirror of the handle's bookkeeping (csrc/w2a_bookkeeping.h)
         self.known_day = -1        # W2A_Q_LOCKSTEP_DAY
         self.lock = False          # W2A_Q_LOCKSTEP
-        self.bound, self.bound_known, self.foreign, self.auto_note = 0, 0, False, None
         self.graph_canon = self.graph_packed = self.graph_autoreset = False
-        self.graph_note = None
         self.pk_valid, self.canon_valid, self.poisoned = False, True, False
         self.order_set = False
         self.rm_valid = False
@@ -137,7 +133,7 @@ class HandleModel:
         return self.graph_canon or self.graph_packed
 
     def _can_pack(self) -> bool:
-        return self.bound <= 65535 and self.uni_nd > 0 and self.lock and not self.graph_canon
+        return self.uni_nd > 0 and self.lock and not self.graph_canon  # (budgets do not matter: the kernel serves any)
 
     def _ensure_canonical(self):
         self.canon_valid = True
@@ -190,43 +186,6 @@ class HandleModel:
         if self.write_obs:
             self.obs[sel] = rows[sel].astype(np.float32)
 
-    def _note_budgets(self, cand, mode, sticky):
-        if mode == BUDGET_CENTERED and sticky:  # a sticky random walk: no bound, and none can be restored
-            self.bound = self.bound_known = INF
-            return
-        if self.bound != INF:
-            self.bound_known = self.bound
-        if cand < 0:
-            self.bound = INF
-            return
-        if mode == BUDGET_CENTERED:
-            cand = cand + cand // 2 + 1
-        if self.bound == INF:  # out of sight right now: what this reset can draw joins what a later statement restores
-            if self.bound_known != INF and cand > self.bound_known:
-                self.bound_known = cand
-            return
-        if cand > self.bound:
-            self.bound = cand
-
-    def note_set_budget_bound(self, b):
-        if b < 0:
-            if self.bound != INF:
-                self.bound_known = self.bound
-            self.bound = INF
-            return
-        if self.foreign:  # the first statement after w2a_invalidate covers the whole restored buffer
-            self.bound = self.bound_known = b
-            self.foreign = False
-        else:
-            prev = self.bound if self.bound != INF else self.bound_known
-            if prev == INF:
-                return
-            self.bound = max(b, prev)
-        if self.auto_note is not None:  # the handle's autoreset parameters go on handing out their budgets
-            self._note_budgets(*self.auto_note)
-        if self.graph_note is not None:  # ... and so do the ones a recorded autoreset step was captured with
-            self._note_budgets(*self.graph_note)
-
     def _note_launch_reset(self, masked):
         """launch_reset for from_tuples != 2 (bk_reset + bk_end_call)."""
         self.rm_valid = False
@@ -240,12 +199,6 @@ class HandleModel:
                 self.known_day = 0
         self._end_call()
 
-    def _note_cfg(self, cfg, set_autoreset=False):
-        args = (cfg[3] if cfg[3] >= 0 else self.b0_max, cfg[4], cfg[5])
-        if set_autoreset:  # w2a_set_autoreset: remembered by the handle
-            self.auto_note = args
-        self._note_budgets(*args)
-
     def _device_reset(self, sel, restart, masked=False):
         """w2a_reset_device_rng on the selected envs with self.reset_cfg (+ the relabelling sort in sorted mode).
         masked: a mask was PASSED (whatever it selects: the handle cannot see its contents)."""
@@ -256,7 +209,6 @@ class HandleModel:
         self.episode_no[idx] = ep
         self.sticky[idx] = so
         self._assign(idx, cw, yi, cc, sm, b)
-        self._note_cfg(self.reset_cfg)
         self._note_launch_reset(masked=masked)
         if self.episode_order == "sorted":
             assert sel.all()
@@ -309,7 +261,6 @@ class HandleModel:
             self._leave_lockstep()
         self.reset_cfg = self.device_cfg(seed, options)
         self._device_reset(sel, restart=True, masked=mask is not None)
-        self._note_cfg(self.reset_cfg, set_autoreset=True)  # w2a_set_autoreset after the reset
         self.was_reset = True
 
     def reset_tuples(self, seed, ep, mask=None, options=None):
@@ -325,13 +276,10 @@ class HandleModel:
             bud = np.broadcast_to(np.asarray(ep["budget"], np.int64), (self.n,))
         self.episode_no[idx] += 1  # cold.w + 1; the sticky budget stays
         self._assign(idx, arr["county_w"][idx], arr["year_i"][idx], arr["coef_col"][idx], arr["sample"][idx], bud[idx])
-        self._note_budgets(-1, BUDGET_FIXED, 0)  # budgets in device memory: unknown to the handle ...
         self._note_launch_reset(masked=mask is not None)
-        self.note_set_budget_bound(int(max(int(bud[sel].max()) if sel.any() else 0, 0)))  # ... until the caller says
         self.py_order_stale = True
         if self.autoreset in ("same_step", "next_step"):
             self.reset_cfg = self.device_cfg(seed, options)
-            self._note_cfg(self.reset_cfg, set_autoreset=True)
         self.was_reset = True
 
     # ------------------------------------------------------------------------------------------ step
@@ -361,12 +309,8 @@ class HandleModel:
                 self.graph_packed = True
             else:
                 self.graph_canon = True
-            if flags_autoreset:  # replays go on drawing budgets with the parameters of this moment
+            if flags_autoreset:
                 self.graph_autoreset = True
-                self.graph_note = self.auto_note if self.graph_note is None else (
-                    max(self.graph_note[0], self.auto_note[0]),
-                    BUDGET_CENTERED if BUDGET_CENTERED in (self.graph_note[1], self.auto_note[1]) else self.auto_note[1],
-                    int(bool(self.graph_note[2]) or bool(self.auto_note[2])))
         nxt = self.known_day + 1 if (not flags_autoreset and self.known_day >= 0 and self.known_day + 1 < self.uni_nd) else -1
         if self.any_graph:
             nxt = -1
@@ -598,10 +542,6 @@ class HandleModel:
         return d
 
     def note_invalidate(self):
-        self.bound = self.bound_known = INF
-        self.foreign = True
-        # w2a_invalidate scans the buffer itself: the largest budget it holds, current and sticky
-        self.note_set_budget_bound(int(max(int(self.V.budget.max()), int(self.sticky.max()), 0)))
         self.known_day, self.lock = -1, False
         self.rm_valid = False
         self.pk_valid, self.canon_valid = False, True
@@ -609,8 +549,8 @@ class HandleModel:
         self._end_call()
 
     def restore(self, d: dict):
-        """env.load_state_dict(...): the arrays come back; the handle forgets what it knew and scans the buffer for its
-        largest budget (w2a_invalidate), and gets the checkpoint's autoreset parameters again."""
+        """env.load_state_dict(...): the arrays come back; the handle forgets what it knew (w2a_invalidate) and gets the
+        checkpoint's autoreset parameters again."""
         for k in self._CKPT:
             if k == "V":
                 for f, v in d["V"].items():
@@ -620,6 +560,4 @@ class HandleModel:
         if not (self.lockstep and self.autoreset == "next_step"):
             self.pending_reset = False
         self.note_invalidate()
-        if self.reset_cfg is not None:
-            self._note_cfg(self.reset_cfg, set_autoreset=True)
         self.py_order_stale = True

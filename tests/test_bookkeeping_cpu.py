@@ -1,12 +1,16 @@
 """The handle's host-side bookkeeping (weather2alert_amd/csrc/w2a_bookkeeping.h -- the header libw2a.so itself compiles)
 on the CPU, under AddressSanitizer + UBSan, against a recording stub that knows which form of the per-env state is really
-current, which day the envs are really on and which budgets they really hold (tests/bookkeeping_check.cpp): random call
+current and which day the envs are really on (tests/bookkeeping_check.cpp): random call
 sequences of every entry point that touches a validity flag (the round-2 advisor found two stale-flag
 bugs of this kind by reading, the GPU sequence fuzz covers the same ground end to end).
 
 Second half: the same program walks the ABSTRACT state space of the header breadth first to closure (nothing sampled).
-Third: MUTANTS of the header -- one rule broken each (a flag not cleared, a day not checked, a bound not kept) -- must
-every one be caught by the same program. That is what says the harness would have seen such a bug."""
+Third: MUTANTS of the header -- one rule broken each (a flag not cleared, a day not checked) -- must
+every one be caught by the same program. That is what says the harness would have seen such a bug.
+
+Round 6: the header no longer knows anything about budgets (the packed kernel serves any budget, csrc/w2a_common.hip.h
+pk_budget16), so the "budgets" walk, its invariant and ten mutants are gone; the walk of what is left grew from two envs and
+two-day episodes to three and three."""
 import os
 import shutil
 import subprocess
@@ -46,23 +50,7 @@ MUTANTS = [
      "if (!masked && b.uni_nd > 0) b.uni_t = 0;"),
     ("rollout to the end keeps the lock-step day", "(day >= 0 && day + n_steps < b.uni_nd && !bk_any_graph(b))",
      "(day >= 0 && !bk_any_graph(b))"),
-    ("a sticky centred budget counts as bounded", "  if (centered && sticky) { b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN; return; }\n", "\n"),
-    ("a sticky random walk is forgotten by the next statement (the r3 rule)",
-     "  if (centered && sticky) { b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN; return; }",
-     "  if (centered && sticky) { if (b.budget_bound != W2A_BK_UNKNOWN) b.budget_bound_known = b.budget_bound; b.budget_bound = W2A_BK_UNKNOWN; return; }"),
-    ("a stated bound forgets earlier sticky budgets", "    b.budget_bound = bound > prev ? bound : prev;", "    b.budget_bound = bound;"),
-    ("budgets in device memory count as known", "  if (cand < 0) { b.budget_bound = W2A_BK_UNKNOWN; return; }\n", "  if (cand < 0) return;\n"),
-    ("a statement after a restore forgets the autoreset parameters",
-     "  if (b.has_auto) bk_note_budgets(b, b.auto_cand, b.auto_centered != 0, b.auto_sticky != 0);\n", "\n"),
-    ("a reset with known arguments while budgets are out of sight is forgotten (round 5 finding)",
-     "    if (b.budget_bound_known != W2A_BK_UNKNOWN && cand > b.budget_bound_known) b.budget_bound_known = cand;\n", "\n"),
-    ("'unknown again' forgets what was known (round 5 finding)",
-     "    if (b.budget_bound != W2A_BK_UNKNOWN) b.budget_bound_known = b.budget_bound;\n    b.budget_bound = W2A_BK_UNKNOWN;\n    return;",
-     "    b.budget_bound = W2A_BK_UNKNOWN;\n    return;"),
-    ("the packed form ignores the budget bound", "return b.pk_static_ok && b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;",
-     "return b.pk_static_ok && b.uni_nd > 0;"),
-    ("the packed form ignores the table limits", "return b.pk_static_ok && b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;",
-     "return b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;"),
+    ("the packed form ignores the table limits", "  return b.pk_static_ok && b.uni_nd > 0;", "  return b.uni_nd > 0;"),
     ("a new visiting order keeps the old tile list", "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; b.rm_valid = 0; }",
      "static inline void bk_order_set(W2aBook &b) { b.has_order = 1; }"),
     ("reset keeps the matrix-core rollout's tile list", "  b.rm_valid = 0;  // new episodes: the feature-row tile list of the matrix-core rollout is stale\n", "\n"),
@@ -80,9 +68,7 @@ MUTANTS = [
     ("after a recorded packed step, nothing keeps the mirror current", "  if (!b.graph_packed) return;\n", "  return;\n"),
     ("a mirror that cannot be kept current is not poisoned", "  } else if (!b.poisoned) {\n    d.poison_mirror();\n    b.poisoned = 1;\n  }", "  }"),
     ("the mirror is re-packed although the batch cannot be packed", "  if (bk_can_pack(b)) {  // the canonical words were modified", "  if (true) {  //"),
-    ("a recorded autoreset step is not remembered", "      b.graph_autoreset = 1;\n", "\n"),
-    ("the parameters a recorded autoreset step draws budgets with are forgotten by the next statement",
-     "  if (b.graph_autoreset) bk_note_budgets(b, b.graph_cand, b.graph_centered != 0, b.graph_sticky != 0);\n", "\n"),
+    ("a recorded autoreset step is not remembered", "    if (autoreset) b.graph_autoreset = 1;\n", "\n"),
     ("an in-kernel autoreset keeps the row counts", "    b.hist_valid = 0;\n  }\n  if (capturing) {", "  }\n  if (capturing) {"),
     ("a relabelling keeps the per-env ranks", "  b.hist_valid = 0;  // ... and so are the per-env ranks inside the feature rows\n", "\n"),
     ("a masked reset leaves the row counts valid", "b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;",
@@ -93,8 +79,11 @@ MUTANTS = [
     ("another order workspace inherits the row counts", "  b.has_order_ws = 1; b.hist_valid = 0;\n", "  b.has_order_ws = 1;\n"),
     ("a failed full reset claims the canonical words it never wrote",
      "  const bool unpacked = (masked || observe_only) && !before.canon_valid;", "  const bool unpacked = !before.canon_valid;"),
-    ("a failed launch after a conversion forgets that the mirror was rewritten",
-     "  if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }", "  if (p.converted == 1) { b.pk_valid = 1; }"),
+    # (round 5's "a failed launch after a conversion forgets that the mirror was rewritten" -- bk_step_rollback without its
+    # `b.poisoned = 0` -- is no longer a mutant: a step could only convert INTO the packed form on a poisoned handle after
+    # w2a_set_budget_bound had made the batch packable again without running bk_end_call, the advisor's round-5 finding;
+    # with that entry point gone, poisoned implies "cannot be packed" at every call boundary and the walk shows the line
+    # unreachable. It stays in the header as written.)
 ]
 
 
@@ -131,13 +120,13 @@ def test_bookkeeping_state_space_walked_to_closure_under_sanitizers(tmp_path):
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
     m = re.search(r"(\d+) reachable abstract states, (\d+) transitions", r.stdout)
     states, edges = int(m.group(1)), int(m.group(2))
-    assert states > 100_000 and edges > 10_000_000, r.stdout[-600:]  # a walk that explores nothing proves nothing
+    assert states > 50_000 and edges > 3_000_000, r.stdout[-600:]  # a walk that explores nothing proves nothing
     print(r.stdout.strip().splitlines()[-1], f"({dt:.0f} s under ASan + UBSan)")
 
 
 def test_every_mutant_of_the_bookkeeping_is_caught(tmp_path):
     """Each mutant must be caught by the random driver or, failing that, by the exhaustive walk (mutants are built without
-    the sanitizers: what is tested here is the harness, and 46 sanitizer builds would dominate the CPU suite)."""
+    the sanitizers: what is tested here is the harness, and three dozen sanitizer builds would dominate the CPU suite)."""
     hdr = open(os.path.join(CSRC, "w2a_bookkeeping.h")).read()
     gxx = shutil.which("g++")
     if gxx is None:

@@ -1442,8 +1442,82 @@ def test_step_is_hipgraph_capturable(dev):
     assert cap.packed_state
     replay_and_compare()
     assert cap.check_status() == 0 and eager.check_status() == 0
+    # Finding 8 of DESIGN section 4 (round 5, GPU fuzz seed 505 sequence 357), as a named regression: a checkpoint restored
+    # over a POISONED mirror. The caller's copy covers the whole state buffer, the mirror's day words included, so real days
+    # come back; the handle must not go on believing its poison is in place -- a replay has to refuse, not step stale state.
+    ck = cap.state_dict()                          # taken while the batch is packable (the mirror holds real days)
+    cap.reset(seed=12, options={"mask": m})        # lock step ends: the mirror is poisoned on the device
+    assert not cap.packed_state
+    cap.load_state_dict(ck)                        # real days over the poison; lock step is not known after a restore
+    assert not cap.packed_state and cap.check_status() == 0
+    before = (cap._obs.clone(), cap._reward.clone(), cap.state())
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert int(cap.status_word.item()) & _ffi.ST_STALE_GRAPH  # the device flag a loop can assert on without check_status()
+    with pytest.raises(RuntimeError, match="hipGraph"):
+        cap.check_status()
+    after = cap.state()
+    assert torch.equal(cap._obs, before[0]) and torch.equal(cap._reward, before[1])
+    for k in after:
+        assert torch.equal(after[k], before[2][k]), k
+    # The advisor's round-5 finding: a whole-batch reset with the caller's TUPLES (budgets in device memory) on a handle with
+    # a recorded packed step. Until round 5 the budgets switched the packed form off and the call ended with the mirror
+    # poisoned although the batch was in lock step again. Now any whole-batch reset leaves it packed: the replay steps.
+    rng = np.random.default_rng(3)
+    county = rng.integers(0, ct.S, n2)
+    ep = dict(county_w=np.asarray(ct.fips_to_weather)[county], year_i=rng.integers(0, ct.Y, n2), coef_col=county,
+              sample=rng.integers(0, ct.n_samples, n2), budget=rng.integers(0, 70000, n2))
+    eager.reset(seed=13, options={"episodes": ep})
+    cap.reset(seed=13, options={"episodes": ep})
+    assert cap.packed_state and q(cap, _ffi.Q_LOCKSTEP) == 1
+    replay_and_compare()
+    same_state()
+    assert int(cap.state()["t"].min()) == G2 and cap.check_status() == 0 and eager.check_status() == 0
+    # Only w2a_step is recorded: a reset, a rollout or a relabelling inside a capture is refused (a replay would run them
+    # without the handle's bookkeeping) and leaves the handle as it was
+    for what in ("reset", "rollout"):
+        with pytest.raises(_ffi.W2AError, match="recording a hipGraph"):
+            with torch.cuda.graph(torch.cuda.CUDAGraph()):
+                cap.reset(seed=14) if what == "reset" else cap.rollout(pol, n_steps=2)
+    replay_and_compare()
+    assert cap.check_status() == 0
     eager.close()
     cap.close()
+    # A loop whose episode boundaries the HOST drives (the default in lock step: it counts days and launches the reset)
+    # cannot be recorded: step() raises instead of recording a loop that would reset at a fixed position of the graph
+    host = HeatAlertVecEnv(n2, tables=ct, device=dev)  # autoreset="same_step", lockstep=True by default
+    host.reset(seed=8)
+    host.step(acts2[0])
+    g5 = torch.cuda.CUDAGraph()
+    with pytest.raises(_ffi.W2AError, match="lockstep=False"):
+        with torch.cuda.graph(g5):
+            host.step(acts2[0])
+    assert host._steps_in_episode == 1  # the host's day count did not run ahead
+    host.step(acts2[1])
+    assert host.check_status() == 0
+    host.close()
+    # record_steps(): the same capture with the status word read behind every replay -- a stale block raises at the next
+    # replay (or at finish()) instead of going unnoticed
+    rec = HeatAlertVecEnv(n2, tables=ct, device=dev, lockstep=False)
+    rec.reset(seed=8)
+    k = [0]
+
+    def one_day():
+        rec.step(acts2[k[0] % G2])
+        k[0] += 1
+
+    block = rec.record_steps(one_day, G2)
+    assert rec.last_step_kernel == "k_step64<packed>"
+    for _ in range(3):
+        block.replay()
+    block.finish()
+    assert int(rec.state()["t"].min()) == (1 + 3 * G2) % ct.T
+    rec.reset(seed=9, options={"mask": m})  # the batch leaves lock step: the recorded packed steps can no longer run
+    block.replay()                          # (raises nothing yet: the status of THIS replay is read behind the next one)
+    with pytest.raises(RuntimeError, match="hipGraph"):
+        block.replay()
+    block.finish()
+    rec.close()
     # A capture that starts on the canonical form (no eager step since the reset) records the canonical kernel -- no
     # conversion is ever recorded -- and such a handle keeps to the canonical form for good.
     eager = HeatAlertVecEnv(n2, tables=ct, device=dev, autoreset="disabled")
@@ -1525,7 +1599,8 @@ def test_packed_state_at_the_limits_of_its_bit_fields(dev):
     """The lock-step mirror packs used / streak into 8 bits each, the budget into 16, the posterior draw into 10 and the day
     into a tile word: tables at exactly those limits -- 255-day episodes, 1 024 draws, budget 65 535, an alert every day
     (used and streak reach 254, the 14-day history is all ones) -- must still be bit-identical to the canonical-form kernel
-    and, on a sample, agree with the oracle; one more unit of budget (65 536) and the handle must not pack at all."""
+    and, on a sample, agree with the oracle. (65 535 is the escape value of the 16-bit budget field: every lane of this
+    batch reads its budget from the canonical words. Budgets on both sides of it: test_packed_step_serves_any_budget.)"""
     from weather2alert_amd import HeatAlertVecEnv, _ffi
 
     sd = synth.make_synth("linear", n_fips=6, years=[2006, 2007], n_samples=1024, n_days=255, seed=3, extra_confounder_fips=2)
@@ -1569,18 +1644,124 @@ def test_packed_state_at_the_limits_of_its_bit_fields(dev):
     assert A.check_status() == 0 and B.check_status() == 0
     A.close()
     B.close()
-    # one more unit of budget does not fit 16 bits: no packed step, same results (fresh envs: a budget sticks, Q9)
-    A = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="auto")
-    B = HeatAlertVecEnv(n, tables=ct, device=dev, step_kernel="unpacked")
-    A.reset(seed=2, options={"budget": 65536})
-    B.reset(seed=2, options={"budget": 65536})
-    assert q(A, _ffi.Q_PACKED_ELIGIBLE) == 0
-    for t in range(5):
-        oa, ra, _, _, _ = A.step(ones)
-        ob, rb, _, _, _ = B.step(ones)
-        assert torch.equal(oa, ob) and torch.equal(ra, rb) and not A.packed_state
-    assert int(A.state()["budget"].min()) == 65536 and A.check_status() == 0 and B.check_status() == 0
     print(f"packed limits: max |reward - oracle| = {worst:.2e}")
+
+
+def test_packed_step_serves_any_budget(dev):
+    """The lock-step mirror has 16 bits for a budget; budgets it cannot hold are marked there (0xFFFF) and read from the
+    canonical words by the lane that needs them (csrc/w2a_common.hip.h pk_budget16, w2a_step64.hip.h s64_load_packed), so the
+    host keeps no bound on budgets any more (round 6: until then eleven fields of the bookkeeping, and four of its eight
+    known holes, were about that bound). One packed batch holding budgets {0, 9, 65 534, 65 535, 65 536, 70 000, 2^24}
+    side by side, reached the three ways that used to need a statement or a scan:
+      (a) handed over in DEVICE MEMORY (reset with injected tuples) and nothing stated about them;
+      (b) a RESTORED CHECKPOINT whose large budgets live on as sticky budgets and come back at the next device reset;
+      (c) a STICKY CENTRED random walk (env.py:167-178, Q9: every episode re-samples around the last sampled value)
+          drawn inside the packed kernel's own autoreset epilogue, across the 65 535 border in both directions.
+    Everything bit for bit the canonical-form kernel (step_kernel="unpacked") and, against the oracle, observations exact
+    -- the remaining_budget column included -- and rewards within 1e-5."""
+    from oracle.sequence_model import draw_episodes
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007, 2008], n_samples=6, n_days=12, seed=21, extra_confounder_fips=3)
+    ct = tables.compile_from_synth(sd)
+    n, T = 131072 + 13, 12
+    BUDGETS = np.array([0, 9, 65534, 65535, 65536, 70000, 1 << 24], np.int64)
+    i_rem = ct.feature_names.index("remaining_budget")
+    rng = np.random.default_rng(5)
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+
+    def oracle_for(env, idx=None):
+        st = {k: v.cpu().numpy() for k, v in env.state().items()}
+        if idx is not None:
+            st = {k: v[idx] for k, v in st.items()}
+        V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+        V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
+        return V, st
+
+    def run_episode(A, B, V, idx, acts, what):
+        """one episode of both envs, A checked against B bit for bit and against the oracle on `idx`"""
+        worst = 0.0
+        for t in range(T):
+            a = acts(t)
+            oa, ra, da, _, _ = A.step(a)
+            ob, rb, db, _, _ = B.step(a)
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (what, t)
+            assert A.last_step_kernel == "k_step64<packed>" and B.last_step_kernel == "k_step64", (what, t)
+            an = a.cpu().numpy() if idx is None else a[torch.as_tensor(idx, device=dev)].cpu().numpy()
+            obs_o, r_o, done_o, _ = V.step(an.astype(np.int64))
+            got_r = ra.cpu().numpy() if idx is None else ra.cpu().numpy()[idx]
+            worst = max(worst, float(np.abs(got_r.astype(np.float64) - r_o).max()))
+            if t < T - 1:  # (the terminal step keeps the stale row, Q6; with an autoreset it shows the next episode's first)
+                got_o = oa.cpu().numpy() if idx is None else oa.cpu().numpy()[idx]
+                assert np.array_equal(got_o, obs_o.astype(np.float32)), (what, t)
+                assert np.array_equal(got_o[:, i_rem], (V.budget - V.used).astype(np.float32)), (what, t)
+        assert worst <= REWARD_TOL, (what, worst)
+        return worst
+
+    # ---- (a) budgets in device memory, nothing stated
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel="auto")
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel="unpacked")
+    county = rng.integers(0, ct.S, n)
+    ep = dict(county_w=np.asarray(ct.fips_to_weather)[county], year_i=rng.integers(0, ct.Y, n), coef_col=county,
+              sample=rng.integers(0, ct.n_samples, n), budget=BUDGETS[np.arange(n) % len(BUDGETS)])
+    A.reset(seed=1, options={"episodes": ep})
+    B.reset(seed=1, options={"episodes": ep})
+    V, st = oracle_for(A)
+    assert np.array_equal(st["budget"], ep["budget"])
+    w_a = run_episode(A, B, V, None, lambda t: ones, "device-memory budgets")  # an alert every day: budgets 0 and 9 run out
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    used = sa["used"].cpu().numpy()
+    assert np.array_equal(used, np.minimum(ep["budget"], T))  # every attempt within budget is granted (Q5)
+    assert np.array_equal(sa["at_budget"].cpu().numpy(), np.minimum(ep["budget"], T - 1) == ep["budget"])  # env.py:242, before the action
+    # ---- (b) a checkpoint with these budgets as STICKY ones, restored into a fresh handle, then a sticky device reset
+    for e in (A, B):
+        e.reset(seed=2, options={"budget": int(BUDGETS[-1])})  # sticky from here on (Q9): every env holds 2^24
+        e.step(ones)
+    ck = A.state_dict()
+    A2 = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel="auto")
+    A2.reset(seed=77)
+    A2.load_state_dict(ck)   # (w2a_invalidate: host-side only since ABI 18, no scan of the buffer)
+    A2.reset(seed=3)
+    B.reset(seed=3)
+    V, st = oracle_for(A2)
+    assert (st["budget"] == 1 << 24).all() and (st["sticky_budget"] == 1 << 24).all()
+    w_b = run_episode(A2, B, V, None, lambda t: ones, "restored sticky budgets")
+    A2.close()
+    A.close()
+    B.close()
+    # ---- (c) the sticky centred walk, drawn by the packed kernel's own autoreset epilogue
+    A = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="same_step", lockstep=False, step_kernel="auto")
+    B = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="same_step", lockstep=False, step_kernel="unpacked")
+    opts = {"budget": 60000, "sample_budget": True, "sample_budget_type": "centered"}
+    A.reset(seed=4, options=opts)
+    B.reset(seed=4, options=opts)
+    idx = np.unique(np.concatenate([np.arange(0, n, 97), [n - 1]]))
+    g = torch.Generator(device=dev).manual_seed(9)
+    sticky = np.full(len(idx), -1, np.int64)
+    w_c, crossed_up, crossed_down = 0.0, 0, 0
+    for episode in range(5):
+        V, st = oracle_for(A, idx)
+        # the episode the kernel drew is the one the restated device RNG draws, budget chain included
+        cw, yi, cc, sm, b, sticky_new = draw_episodes(ct, A._reset_cfg, idx, np.full(len(idx), episode), sticky, False)
+        assert np.array_equal(st["budget"], b) and np.array_equal(st["sticky_budget"], sticky_new), episode
+        assert np.array_equal(st["county_w"], cw) and np.array_equal(st["sample"], sm), episode
+        if episode:
+            crossed_up += int(((sticky < 65535) & (b >= 65535)).sum())
+            crossed_down += int(((sticky >= 65535) & (b < 65535)).sum())
+        sticky = sticky_new
+        acts = [(torch.rand(n, device=dev, generator=g) < 0.5).to(torch.int32) for _ in range(T)]
+        w_c = max(w_c, run_episode(A, B, V, idx, lambda t: acts[t], f"centred walk, episode {episode}"))
+        assert A.packed_state
+    assert crossed_up > 10 and crossed_down > 10, (crossed_up, crossed_down)
+    assert int(b.max()) > 100000 and int(b.min()) < 30000, (int(b.min()), int(b.max()))
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert A.check_status() == 0 and B.check_status() == 0
+    print(f"any budget on the packed form: max |reward - oracle| = {max(w_a, w_b, w_c):.2e}; the sticky centred walk crossed "
+          f"65 535 upwards {crossed_up} and downwards {crossed_down} times in the sample")
     A.close()
     B.close()
 

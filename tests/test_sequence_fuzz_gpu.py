@@ -1,6 +1,6 @@
 """Model-based call-sequence fuzz of the libw2a handle: 1000 random sequences of 30-80 operations each
 -- resets (device RNG / injected tuples, masked / unmasked), steps in every kernel form and autoreset mode, partial and
-whole rollouts, state(), checkpoints, w2a_invalidate / w2a_set_budget_bound, episode_order="sorted", the posterior-mean
+whole rollouts, state(), checkpoints, w2a_invalidate, episode_order="sorted", the posterior-mean
 reward with each kernel, hipGraph captures (of canonical and of packed steps) with replays right away and later in the
 sequence -- mirrored on oracle/sequence_model.HandleModel; outputs compared
 after every operation, w2a_query against what the sequence implies (tools/sequence_fuzz.py is the long form).
@@ -74,12 +74,13 @@ def test_policy_loop_over_a_ragged_batch_raises_no_status_bit():
         env.close()
 
 
-def test_restored_sticky_budget_above_16_bits_never_reaches_the_packed_state():
+def test_restored_sticky_budget_above_16_bits_is_served_by_the_packed_kernel():
     """Finding 5 of the fuzz (round 4, sequence 77 of seed 99): episodes with a sticky budget of 65 721, a checkpoint
     restore (w2a_invalidate) after which nothing was stated about budgets, a reset with injected tuples whose small
     budgets the caller then stated -- the handle took that as covering the whole buffer, and the next sticky device
-    reset handed 65 721 to the 16-bit packed form: rewards off by 5. w2a_invalidate now scans the restored buffer
-    itself (current and sticky budgets)."""
+    reset handed 65 721 to the 16-bit packed form: rewards off by 5. Rounds 4 and 5 kept such budgets away from the packed
+    form (a scan of the restored buffer, a bound, statements); since round 6 the packed kernel reads budgets its 16-bit
+    field cannot hold from the canonical words, nothing is stated or scanned, and the same sequence runs PACKED and right."""
     import numpy as np
 
     from oracle import heatalert_oracle as O
@@ -91,25 +92,27 @@ def test_restored_sticky_budget_above_16_bits_never_reaches_the_packed_state():
     env = HeatAlertVecEnv(n, tables=ct, device=dev, autoreset="disabled", step_kernel="wide")
     env.reset(seed=1, options={"budget": 65721})  # sticky from here on (Q9)
     env.step(torch.ones(n, dtype=torch.int32, device=dev))
+    assert env.packed_state
     env.state()
-    _ffi.check(env._lib.w2a_invalidate(env._h, env._stream()), "w2a_invalidate")  # as after a restore; nothing stated afterwards
-    assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 0  # the library found 65 721 in the buffer by itself
+    _ffi.check(env._lib.w2a_invalidate(env._h, env._stream()), "w2a_invalidate")  # as after a restore
+    assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 1  # a property of the tables, not of budgets
     rng = np.random.default_rng(0)
     county = rng.integers(0, ct.S, n)
     env.reset(seed=2, options={"episodes": dict(county_w=np.asarray(ct.fips_to_weather)[county], year_i=rng.integers(0, ct.Y, n),
                                                 coef_col=county, sample=rng.integers(0, ct.n_samples, n),
                                                 budget=rng.integers(0, 9, n))})
-    assert env._lib.w2a_query(env._h, _ffi.Q_PACKED_ELIGIBLE) == 0  # the sticky 65 721 is still in the buffer
     env.reset(seed=3)  # device RNG, sticky: every env gets 65 721 again
     st = {k: v.cpu().numpy() for k, v in env.state().items()}
     assert (st["budget"] == 65721).all()
     V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
     V.reset(st["county_w"], st["year_i"], st["coef_col"], st["sample"], st["budget"])
-    for _ in range(3):
+    for t in range(3):
         a = (rng.random(n) < 0.5).astype(np.int32)
-        _, r, _, _, _ = env.step(torch.as_tensor(a, device=dev))
-        _, r_o, _, _ = V.step(a)
-        assert np.abs(r.cpu().numpy() - r_o).max() <= 1e-5 and not env.packed_state
+        o, r, _, _, _ = env.step(torch.as_tensor(a, device=dev))
+        o_o, r_o, _, _ = V.step(a)
+        assert np.abs(r.cpu().numpy() - r_o).max() <= 1e-5 and env.packed_state
+        assert np.array_equal(o.cpu().numpy(), o_o.astype(np.float32)), t
+    assert env.check_status() == 0
     env.close()
 
 

@@ -11,9 +11,9 @@ ROW_FLOATS = 32
 OK = 0
 ST_BAD_EPISODE, ST_BAD_ACTION, ST_STEP_AFTER_DONE, ST_STALE_GRAPH = 1, 2, 4, 8
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
-STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED, STEP_UNPACKED, STEP_NEXT_STEP = 1, 2, 8, 16, 32, 64, 128, 256
+STEP_AUTORESET, STEP_NO_OBS, STEP_CLASSIC, STEP_REWARD_GIVEN, STEP_WIDE, STEP_SKIP_FINISHED, STEP_UNPACKED, STEP_NEXT_STEP, STEP_NO_CAPTURE = 1, 2, 8, 16, 32, 64, 128, 256, 512
 S64_MIN_ENVS = 131072  # w2a_step picks the 64-envs-per-wave kernel from this batch size on (csrc/w2a_step64.hip.h)
-ABI_VERSION = 17
+ABI_VERSION = 18
 FIX_BITS = {"alert_2wks": 1, "lag": 2, "penalty": 4, "obs": 8, "augment": 16}  # + "budget" (sticky = 0)
 BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 
@@ -22,7 +22,7 @@ SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
     "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order_attach", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
-    "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward", "w2a_set_posterior_kernel", "w2a_invalidate", "w2a_query", "w2a_set_budget_bound", "w2a_rollout_mfma_workspace_bytes", "w2a_rollout_mfma_prepare",
+    "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward", "w2a_set_posterior_kernel", "w2a_invalidate", "w2a_query", "w2a_rollout_mfma_workspace_bytes", "w2a_rollout_mfma_prepare",
 ]
 Q_LOCKSTEP_DAY, Q_PACKED_ELIGIBLE, Q_PACKED_CURRENT, Q_CANONICAL_CURRENT, Q_LAST_ROLLOUT_KERNEL, Q_LAST_STEP_KERNEL, Q_LOCKSTEP = 0, 1, 2, 3, 4, 5, 6
 PM_KERNELS = {"vector": 0, "matrix": 1, "matrix_i8": 2}  # W2A_PM_VECTOR, W2A_PM_MATRIX_F64, W2A_PM_MATRIX_I8
@@ -118,8 +118,6 @@ def load(build_if_missing: bool = True):
     lib.w2a_posterior_mean_reward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.w2a_set_posterior_kernel.restype = C.c_int
     lib.w2a_set_posterior_kernel.argtypes = [vp, C.c_int]
-    lib.w2a_set_budget_bound.restype = C.c_int
-    lib.w2a_set_budget_bound.argtypes = [vp, i64]
     lib.w2a_rollout_mfma_workspace_bytes.restype = C.c_size_t
     lib.w2a_rollout_mfma_workspace_bytes.argtypes = [i64, i64, i32, i32]
     lib.w2a_rollout_mfma_prepare.restype = C.c_int

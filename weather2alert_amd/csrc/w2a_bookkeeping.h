@@ -1,6 +1,9 @@
 // w2a_bookkeeping.h -- host-side bookkeeping of a libw2a handle: which form of the per-env step state is current,
-// what the handle knows about days and budgets, which derived structures (column grouping, visiting order, tile lists)
+// what the handle knows about days, which derived structures (column grouping, visiting order, tile lists)
 // still belong to the episodes the envs hold, and -- from that -- which kernel an entry point may launch.
+// (Nothing about budgets: until round 5 the handle kept an upper bound of every budget in the state buffer, because the
+// packed form held them in 16 bits -- eleven fields and three functions of this header, four of its eight known holes.
+// The packed kernel now serves any budget by itself: w2a_common.hip.h, pk_budget16.)
 //
 // Plain C++17, no HIP: the decisions live here, the launches behind a small `Dev` interface, so that the same code
 // runs (a) inside libw2a.so (w2a_kernels.hip: Dev = the HIP launches on the caller's stream) and (b) on a CPU under
@@ -21,9 +24,6 @@
 
 #include <stdint.h>
 
-#define W2A_BK_UNKNOWN INT64_MAX
-#define W2A_BK_PACKED_MAX_BUDGET 65535  // the lock-step mirror holds budgets in 16 bits
-
 struct W2aBook {
   // Per-env step state exists in two forms (w2a_common.hip.h, StateArrays): the canonical words and the 16-B lock-step
   // mirror. At least one of them is always current; both after a read-back of the packed form.
@@ -37,14 +37,6 @@ struct W2aBook {
   int32_t uni_t;         // that day while the HOST knows it, else -1 (lock may still hold: after the terminal step, and
                          // on any handle with a recorded graph, whose replays advance days behind the host's back)
   int32_t uni_nd;        // the one episode length of the tables, -1 if (county, year) pairs differ in length
-  int32_t b0_max;        // largest default budget of the tables
-  int64_t budget_bound;        // no env's budget exceeds this (W2A_BK_UNKNOWN: budgets came over in device memory)
-  int64_t budget_bound_known;  // its last known value (w2a_set_budget_bound restores knowledge from it; W2A_BK_UNKNOWN:
-                               // no bound can be known -- a sticky random walk of budgets -- until w2a_invalidate)
-  int foreign;           // the state buffer was replaced by the caller (w2a_invalidate) and no bound was stated since
-  int has_auto;          // w2a_set_autoreset was called: in-kernel autoresets keep drawing budgets with these arguments,
-  int64_t auto_cand;     // whatever is stated about the budgets the buffer holds NOW
-  int auto_centered, auto_sticky;
   // hipGraphs. A recorded step kernel is tied to the FORM of the state it steps, and a replay runs it without any of
   // this bookkeeping. So the form a recorded kernel reads must be current whenever a replay can happen = at every
   // boundary between two API calls:
@@ -54,12 +46,11 @@ struct W2aBook {
                          // the kernel reads the day from the mirror, so replays advance it themselves): from now on the
                          // mirror is the primary form -- at the end of every API call either it is current and the
                          // canonical words count as a scratch copy (canon_valid = 0: a replay may outdate them), or, where
-                         // the batch can no longer be packed (lock step lost, budgets out of sight), its day words are
-                         // POISONED so that a replay raises W2A_ST_STALE_GRAPH instead of stepping stale state
+                         // the batch can no longer be packed (lock step lost: a masked reset, a restored checkpoint),
+                         // its day words are POISONED so that a replay raises W2A_ST_STALE_GRAPH instead of stepping
+                         // stale state
   int graph_autoreset;   // a recorded step carried W2A_STEP_AUTORESET: replays re-draw episodes at any time -- a column
-                         // grouping, a tile list, row counts are never again reported valid -- and draw their budgets
-  int64_t graph_cand;    // with the w2a_set_autoreset parameters of the moment they were recorded (kernel arguments),
-  int graph_centered, graph_sticky;  // whatever is set or stated later: the largest / widest of them, kept like auto_*
+                         // grouping, a tile list, row counts are never again reported valid
   int poisoned;          // the mirror's day words hold the poison value
   int perm_valid;        // the column grouping (w2a_group_by_column) belongs to the episodes the envs hold
   int has_order;         // a visiting order exists (any permutation is correct; it may be stale = unsorted)
@@ -72,13 +63,10 @@ struct W2aBook {
 enum { W2A_BK_STEP_CLASSIC = 0, W2A_BK_STEP_WIDE = 1, W2A_BK_STEP_PACKED = 2 };
 enum { W2A_BK_ROLLOUT_4LANE = 0, W2A_BK_ROLLOUT_WIDE = 1, W2A_BK_ROLLOUT_MFMA = 2 };
 
-static inline void bk_init(W2aBook &b, bool pk_static_ok, int32_t uni_nd, int32_t b0_max) {
+static inline void bk_init(W2aBook &b, bool pk_static_ok, int32_t uni_nd) {
   b.pk_valid = 0; b.canon_valid = 1; b.pk_static_ok = pk_static_ok ? 1 : 0;
-  b.lock = 0; b.uni_t = -1; b.uni_nd = uni_nd; b.b0_max = b0_max;
-  b.budget_bound = 0; b.budget_bound_known = 0; b.foreign = 0;
+  b.lock = 0; b.uni_t = -1; b.uni_nd = uni_nd;
   b.graph_canon = 0; b.graph_packed = 0; b.graph_autoreset = 0; b.poisoned = 0;
-  b.graph_cand = 0; b.graph_centered = 0; b.graph_sticky = 0;
-  b.has_auto = 0; b.auto_cand = 0; b.auto_centered = 0; b.auto_sticky = 0;
   b.perm_valid = 0; b.has_order = 0; b.rm_valid = 0; b.has_order_ws = 0; b.hist_valid = 0;
   b.last_step_kernel = -1; b.last_rollout_kernel = -1;
 }
@@ -97,61 +85,9 @@ static inline void bk_canonical_modified(W2aBook &b, bool keeps_lockstep) {
   if (!keeps_lockstep) { b.lock = 0; b.uni_t = -1; }
 }
 
-// Budgets. The packed form holds budgets in 16 bits, so the handle keeps an upper bound of every budget the state buffer
-// holds -- the current episodes' AND the sticky ones (cold.z) that later device-RNG resets may hand out again
-// (env.py:167-170, Q9). It only ever sees reset ARGUMENTS:
-//   `cand`     the largest budget a reset with these arguments can draw by itself (< 0: a caller's array in device
-//              memory: the current budgets are unknown until w2a_set_budget_bound, the sticky ones are untouched);
-//   centered   W2A_BUDGET_CENTERED; with `sticky` the budget is a random walk (each episode re-samples around the last
-//              sampled value, also inside the kernels): no bound exists, and none can be restored by a later statement
-//              about the CURRENT budgets, because the unbounded values live on as sticky budgets
-//              (found by tests/bookkeeping_check.cpp: centred sticky episodes, then w2a_reset + w2a_set_budget_bound,
-//              then a sticky device reset handed a budget above 65535 to the packed kernel).
-static inline void bk_note_budgets(W2aBook &b, int64_t cand, bool centered, bool sticky) {
-  if (centered && sticky) { b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN; return; }
-  if (b.budget_bound != W2A_BK_UNKNOWN) b.budget_bound_known = b.budget_bound;
-  if (cand < 0) { b.budget_bound = W2A_BK_UNKNOWN; return; }
-  if (centered) cand = cand + cand / 2 + 1;
-  if (b.budget_bound == W2A_BK_UNKNOWN) {
-    // budgets are out of sight right now, but what THIS reset can draw is known and may live on as sticky budgets: it
-    // must be part of what a later statement about the hidden budgets restores (found by the budget-bound invariant of
-    // tests/bookkeeping_check.cpp, round 5: budgets in device memory, a sticky device reset drawing 60 000, another
-    // hand-over with a stated bound of 9 -- the bound came back as 9 with 60 000 still in cold.z)
-    if (b.budget_bound_known != W2A_BK_UNKNOWN && cand > b.budget_bound_known) b.budget_bound_known = cand;
-    return;
-  }
-  if (cand > b.budget_bound) b.budget_bound = cand;
-}
-// The caller states that no budget handed over in device memory exceeds `bound`. The first statement after
-// bk_invalidate comes from the library itself (w2a_invalidate scans the restored buffer for its largest budget, sticky
-// ones included) and is taken as covering everything; any other is combined with what the handle knew before the
-// budgets went out of sight -- which may be "nothing can be known" (W2A_BK_UNKNOWN: sticky random walk), and then stays so.
-static inline void bk_set_budget_bound(W2aBook &b, int64_t bound) {
-  if (bound < 0) {  // "unknown again": what was known stays the basis of the next statement
-    if (b.budget_bound != W2A_BK_UNKNOWN) b.budget_bound_known = b.budget_bound;
-    b.budget_bound = W2A_BK_UNKNOWN;
-    return;
-  }
-  if (b.foreign) {
-    b.budget_bound = b.budget_bound_known = bound;
-    b.foreign = 0;
-  } else {
-    const int64_t prev = b.budget_bound != W2A_BK_UNKNOWN ? b.budget_bound : b.budget_bound_known;
-    if (prev == W2A_BK_UNKNOWN) return;
-    b.budget_bound = bound > prev ? bound : prev;  // budgets of earlier episodes may live on as sticky budgets
-  }
-  // the statement is about the budgets in the buffer; the autoreset parameters of the handle go on handing out theirs --
-  // and so do the ones a recorded autoreset step was captured with, on every replay
-  if (b.has_auto) bk_note_budgets(b, b.auto_cand, b.auto_centered != 0, b.auto_sticky != 0);
-  if (b.graph_autoreset) bk_note_budgets(b, b.graph_cand, b.graph_centered != 0, b.graph_sticky != 0);
-}
-// w2a_set_autoreset: the parameters in-kernel autoresets draw budgets with from now on
-static inline void bk_set_autoreset(W2aBook &b, int64_t cand, bool centered, bool sticky) {
-  b.has_auto = 1; b.auto_cand = cand; b.auto_centered = centered ? 1 : 0; b.auto_sticky = sticky ? 1 : 0;
-  bk_note_budgets(b, cand, centered, sticky);
-}
+// the tables allow the lock-step mirror at all: one episode length, dims inside its bit fields (any budget is served)
 static inline bool bk_packed_eligible(const W2aBook &b) {
-  return b.pk_static_ok && b.budget_bound <= W2A_BK_PACKED_MAX_BUDGET && b.uni_nd > 0;
+  return b.pk_static_ok && b.uni_nd > 0;
 }
 // the batch may be stepped in the packed form right now
 static inline bool bk_can_pack(const W2aBook &b) { return bk_packed_eligible(b) && b.lock && !b.graph_canon; }
@@ -225,11 +161,7 @@ static inline BkStepPlan bk_step(W2aBook &b, Dev &d, bool wide_wanted, bool auto
   if (capturing) {
     if (packed) b.graph_packed = 1;
     else b.graph_canon = 1;
-    if (autoreset) {  // (w2a_step refuses W2A_STEP_AUTORESET before w2a_set_autoreset: has_auto holds)
-      b.graph_autoreset = 1;
-      if (b.auto_cand > b.graph_cand) b.graph_cand = b.auto_cand;
-      b.graph_centered |= b.auto_centered; b.graph_sticky |= b.auto_sticky;
-    }
+    if (autoreset) b.graph_autoreset = 1;
   }
   // the day every env is on after this call, while the host can know it: a plain step moves all of them to the next
   // day; the terminal step, an in-kernel autoreset, unknown state or a recorded graph end the knowledge of the DAY (lock
@@ -262,7 +194,6 @@ static inline void bk_step_rollback(W2aBook &b, const W2aBook &before, const BkS
   const W2aBook after = b;  // conservative: keep what was recorded
   b = before;
   b.graph_canon = after.graph_canon; b.graph_packed = after.graph_packed; b.graph_autoreset = after.graph_autoreset;
-  b.graph_cand = after.graph_cand; b.graph_centered = after.graph_centered; b.graph_sticky = after.graph_sticky;
   if (bk_any_graph(b)) b.uni_t = -1;
   if (p.converted == 1) { b.pk_valid = 1; b.poisoned = 0; }
   if (p.converted == 2) b.canon_valid = 1;
@@ -307,8 +238,6 @@ static inline void bk_rm_prepared(W2aBook &b) { b.rm_valid = b.graph_autoreset ?
 
 // w2a_invalidate: the caller has overwritten the state buffer (its canonical part): forget every derived form
 static inline void bk_invalidate(W2aBook &b) {
-  b.budget_bound = b.budget_bound_known = W2A_BK_UNKNOWN;  // what was known described another buffer
-  b.foreign = 1;
   b.pk_valid = 0; b.canon_valid = 1; b.lock = 0; b.uni_t = -1; b.perm_valid = 0;
   b.rm_valid = 0;  // feature rows may have changed behind the handle: the matrix-core rollout's tile list is stale
   b.hist_valid = 0;

@@ -72,15 +72,22 @@ struct StateArrays {
   // and advanced by the wave that owns the tile, 4 B per 64 envs) -- in device memory, so that a step recorded into a
   // hipGraph finds the right day on every replay:
   //   pk_hot.x: used[0:8) streak[8:16) hist14[16:30) finished[30]      pk_hot.y: episode return (f32 bits)
-  //   pk_c.x:   budget[0:16) coef_col[16:32)                            pk_c.y:   ep_row[0:22) sample[22:32)
+  //   pk_c.x:   budget16[0:16) coef_col[16:32)                          pk_c.y:   ep_row[0:22) sample[22:32)
   //   pk_day[tile]: the day of envs 64 tile .. 64 tile + 63, or W2A_PK_DAY_POISON (w2a_bookkeeping.h, graph_packed)
   // (last_actual = hist14 & 1; at_budget is derived). Valid for T <= 255, S < 65536, n_samples <= 1024,
-  // S_w * Y < 2^22, budgets <= 65535 -- checked on the host, which also tracks which of the two forms is current.
+  // S_w * Y < 2^22 -- table properties, checked once by w2a_create; the host tracks which of the two forms is current.
+  // Budgets of ANY size are served: budget16 holds budgets 0 .. 65534 themselves and PK_BUDGET_ESCAPE for everything
+  // else (65535 and above; negative values a caller handed over), and the packed kernel then reads the env's canonical
+  // stepc word -- written by every reset path (store_episode), read-only while an episode runs, so never stale. Until
+  // round 5 the host kept an upper bound of every budget in the buffer instead; four of its eight bookkeeping holes were
+  // in that bound.
   uint2 *pk_hot;
   uint2 *pk_c;
   uint32_t *pk_day;
 };
 #define W2A_PK_DAY_POISON 0xFFFFFFFFu
+#define PK_BUDGET_ESCAPE 0xFFFFu
+__device__ __forceinline__ uint32_t pk_budget16(uint32_t budget) { return budget < PK_BUDGET_ESCAPE ? budget : PK_BUDGET_ESCAPE; }
 #define PK_USED(w) ((w) & 255u)
 #define PK_STREAK(w) (((w) >> 8) & 255u)
 #define PK_HIST(w) (((w) >> 16) & 0x3FFFu)

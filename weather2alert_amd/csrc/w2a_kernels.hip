@@ -156,19 +156,38 @@ static void end_call(w2a_env *env, hipStream_t s) {
   HipDev d{env, s};
   bk_end_call(env->bk, d);
 }
-static void ensure_canonical(w2a_env *env, hipStream_t s) {
+// The entry points that launch something other than a step kernel are not recorded into hipGraphs: a replay would run
+// them without the bookkeeping below (a recorded reset re-draws episodes under a column grouping / row counts the handle
+// still calls valid; a recorded conversion converts again from words the replayed steps have outdated). Loops that need
+// episode boundaries inside a graph use W2A_STEP_AUTORESET (include/w2a.h).
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (s && hipStreamIsCapturing(s, &cs) == hipSuccess) return cs != hipStreamCaptureStatusNone;
+  (void)hipGetLastError();
+  return false;
+}
+#define REFUSE_WHILE_CAPTURING(who, stream)                                                                            \
+  do {                                                                                                                 \
+    if (stream_is_capturing((hipStream_t)(stream)))                                                                    \
+      return fail(W2A_ERR_STATE, who ": the stream is recording a hipGraph; only w2a_step can be recorded (episode "    \
+                                     "boundaries inside a graph: W2A_STEP_AUTORESET)");                                \
+  } while (0)
+// something is about to read the canonical words; false (with the error text set): the read would have to record a
+// conversion of the state's form into a hipGraph
+static bool ensure_canonical(w2a_env *env, hipStream_t s, const char *who) {
+  if (!env->bk.canon_valid && stream_is_capturing(s)) {
+    fail(W2A_ERR_STATE, "%s: the state is in its packed lock-step form and a conversion cannot be recorded into a hipGraph", who);
+    return false;
+  }
   HipDev d{env, s};
   bk_ensure_canonical(env->bk, d);
+  return true;
 }
-static void note_budgets(w2a_env *env, int64_t cand, int sample_mode, int sticky) {
-  bk_note_budgets(env->bk, cand, sample_mode == W2A_BUDGET_CENTERED, sticky != 0);
-}
-__global__ void k_table_scan(const int32_t *n_days, const int32_t *B0, int32_t rows, int32_t *out) {  // out: min nd, max nd, max B0
+__global__ void k_table_scan(const int32_t *n_days, int32_t rows, int32_t *out) {  // out: min nd, max nd
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   atomicMin(&out[0], n_days[i]);
   atomicMax(&out[1], n_days[i]);
-  atomicMax(&out[2], B0[i]);
 }
 
 int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *state, size_t state_bytes,
@@ -227,7 +246,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->st.pk_hot = reinterpret_cast<uint2 *>((char *)h->st.stepc + align256(12 * (size_t)num_envs));
   h->st.pk_c = reinterpret_cast<uint2 *>((char *)h->st.pk_hot + align256(8 * (size_t)num_envs));
   h->st.pk_day = reinterpret_cast<uint32_t *>((char *)h->st.pk_c + align256(8 * (size_t)num_envs));
-  bk_init(h->bk, t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22), -1, 0);
+  bk_init(h->bk, t->T <= 255 && t->S < 65536 && t->n_samples <= 1024 && (int64_t)t->S_w * t->Y < (1 << 22), -1);
   h->status = status;
   h->has_autoreset = 0;
   h->perm = nullptr;
@@ -254,16 +273,15 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   if (e3 == hipSuccess && e4 == hipSuccess) e3 = hipMemcpy(&tail_used, scan_flag, sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e3 != hipSuccess || e4 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: init kernels failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : e4)); }
   h->w_tail_used = tail_used;
-  {  // one episode length for every (county, year)? largest default budget? (eligibility of the lock-step mirror)
-    int32_t scan[3] = {0x7FFFFFFF, 0, 0};
-    int32_t *d_scan = reinterpret_cast<int32_t *>(state) + ROWF + 1;  // header words 33..35
+  {  // one episode length for every (county, year)? (eligibility of the lock-step mirror)
+    int32_t scan[2] = {0x7FFFFFFF, 0};
+    int32_t *d_scan = reinterpret_cast<int32_t *>(state) + ROWF + 1;  // header words 33..34
     hipError_t e5 = hipMemcpy(d_scan, scan, sizeof(scan), hipMemcpyHostToDevice);
     const int32_t rows = t->S_w * t->Y;
-    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, t->n_days, t->B0, rows, d_scan);
+    hipLaunchKernelGGL(k_table_scan, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, t->n_days, rows, d_scan);
     if (e5 == hipSuccess) e5 = hipMemcpy(scan, d_scan, sizeof(scan), hipMemcpyDeviceToHost);
     if (e5 != hipSuccess) { delete h; return fail(W2A_ERR_HIP, "w2a_create: table scan failed: %s", hipGetErrorString(e5)); }
     h->bk.uni_nd = (scan[0] == scan[1] && scan[0] > 0) ? scan[0] : -1;
-    h->bk.b0_max = scan[2];
   }
   *out = h;
   return W2A_OK;
@@ -280,6 +298,7 @@ static unsigned grid_for(int64_t n) {
 static int launch_reset(w2a_env *env, ResetArgs &a, void *stream) {
   // arguments first: nothing below may fail for a reason the caller can fix once the bookkeeping has been told of the reset
   if (a.obs && ((uintptr_t)a.obs & 15)) return fail(W2A_ERR_ARG, "reset: obs must be 16-B aligned");
+  REFUSE_WHILE_CAPTURING("reset / observe", stream);
   const W2aBook before = env->bk;
   {
     HipDev d{env, (hipStream_t)stream};
@@ -314,7 +333,6 @@ int w2a_reset(w2a_env *env, const int32_t *county_w, const int32_t *year_i, cons
   memset(&a, 0, sizeof(a));
   a.county_w = county_w; a.year_i = year_i; a.coef_col = coef_col; a.sample = sample; a.budget = budget;
   a.mask = mask; a.obs = obs; a.from_tuples = 1;
-  note_budgets(env, budget ? -1 : env->bk.b0_max, W2A_BUDGET_FIXED, 0);  // caller's budgets live in device memory: unknown
   return launch_reset(env, a, stream);
 }
 
@@ -336,7 +354,6 @@ int w2a_reset_device_rng(w2a_env *env, uint64_t seed, int32_t location, int augm
   int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   a.mask = mask; a.obs = obs; a.from_tuples = 0; a.restart = restart_episodes ? 1 : 0;
-  note_budgets(env, budget_kw >= 0 ? budget_kw : env->bk.b0_max, sample_budget_mode, sticky);
   return launch_reset(env, a, stream);
 }
 
@@ -346,7 +363,6 @@ int w2a_set_autoreset(w2a_env *env, uint64_t seed, int32_t location, int augment
   int rc = fill_cfg(env, env->autoreset, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
   env->has_autoreset = 1;
-  bk_set_autoreset(env->bk, budget_kw >= 0 ? budget_kw : env->bk.b0_max, sample_budget_mode == W2A_BUDGET_CENTERED, sticky != 0);
   return W2A_OK;
 }
 
@@ -370,6 +386,7 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_sort_episodes: NULL argument");
   if (workspace_bytes < w2a_sort_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_sort_episodes: workspace must be 256-B aligned");
+  REFUSE_WHILE_CAPTURING("w2a_sort_episodes", stream);
   const size_t n = (size_t)env->n;
   char *p = (char *)workspace;
   uint64_t *k_in = (uint64_t *)p;  p += align256(8 * n);
@@ -429,6 +446,7 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_group_by_column: NULL argument");
   if (workspace_bytes < w2a_group_workspace_bytes(env->n, env->tb.S, env->tb.n_samples)) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace must be 256-B aligned");
+  REFUSE_WHILE_CAPTURING("w2a_group_by_column", stream);
   const size_t n = (size_t)env->n;
   char *p = (char *)workspace;
   uint32_t *perm = (uint32_t *)p;  p += align256(4 * n);  // first two: stay in use after the call
@@ -510,7 +528,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   memset(&a, 0, sizeof(a));
   a.tb = env->tb; a.st = env->st; a.inv = env->inv; a.perm = env->perm; a.prep = env->prep; a.actions = actions; a.act_dtype = action_dtype;
   a.reward = reward; a.status = env->status; a.n = env->n; a.wd = env->wd; a.tiles = env->tiles; a.n_tiles = env->n_tiles;
-  ensure_canonical(env, (hipStream_t)stream);
+  if (!ensure_canonical(env, (hipStream_t)stream, "w2a_posterior_mean_reward")) return W2A_ERR_STATE;
   hipLaunchKernelGGL(k_pm_prep, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   if (env->pm_kernel == W2A_PM_MATRIX_I8) {
@@ -592,6 +610,7 @@ int w2a_rollout_order_attach(w2a_env *env, void *workspace, size_t workspace_byt
 
 int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_order: NULL argument");
+  REFUSE_WHILE_CAPTURING("w2a_rollout_order", stream);
   const int rc = order_attach(env, workspace, workspace_bytes, "w2a_rollout_order");
   if (rc) return rc;
   const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
@@ -622,6 +641,7 @@ size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, in
 
 int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_mfma_prepare: NULL argument");
+  REFUSE_WHILE_CAPTURING("w2a_rollout_mfma_prepare", stream);
   const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
   if (workspace_bytes < w2a_rollout_mfma_workspace_bytes(env->n, rows, env->tb.S, env->tb.n_samples))
     return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace too small");
@@ -666,6 +686,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
                 float *last_return, float *ret_snapshot, void *stream) {
   if (!env || !policy) return fail(W2A_ERR_ARG, "w2a_rollout: NULL argument");
   if (n_steps <= 0) return fail(W2A_ERR_ARG, "w2a_rollout: n_steps must be positive");
+  REFUSE_WHILE_CAPTURING("w2a_rollout", stream);
   if (policy->kind < W2A_POLICY_NEVER || policy->kind > W2A_POLICY_TABLE) return fail(W2A_ERR_ARG, "w2a_rollout: bad policy kind");
   if (policy->kind == W2A_POLICY_TABLE && (!policy->table || policy->table_R <= 0))
     return fail(W2A_ERR_ARG, "w2a_rollout: tabular policy needs table [T][table_R] and table_R > 0");
@@ -718,6 +739,7 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
                                void *stream) {
   if (!env || !policy) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: NULL argument");
   if (n_steps <= 0) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: n_steps must be positive");
+  REFUSE_WHILE_CAPTURING("w2a_rollout_posterior_mean", stream);
   if (policy->kind < W2A_POLICY_NEVER || policy->kind > W2A_POLICY_TABLE) return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: bad policy kind");
   if (policy->kind == W2A_POLICY_TABLE && (!policy->table || policy->table_R <= 0))
     return fail(W2A_ERR_ARG, "w2a_rollout_posterior_mean: tabular policy needs table [T][table_R] and table_R > 0");
@@ -792,7 +814,7 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
   }
   a.actions = actions; a.alerts = alerts; a.attempts_over_budget = attempts_over_budget;
   a.alert_mask = alert_mask; a.attempt_mask = attempt_mask; a.mask_words = mask_words;
-  ensure_canonical(env, (hipStream_t)stream);
+  if (!ensure_canonical(env, (hipStream_t)stream, "w2a_policy_actions")) return W2A_ERR_STATE;
   hipLaunchKernelGGL(k_policy_actions, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   end_call(env, (hipStream_t)stream);
@@ -802,7 +824,7 @@ int w2a_policy_actions(w2a_env *env, const w2a_policy *policy, int32_t *actions,
 int w2a_get_state(w2a_env *env, const w2a_state_view *view, void *stream) {
   if (!env || !view) return fail(W2A_ERR_ARG, "w2a_get_state: NULL argument");
   int64_t blocks = (env->n + 255) / 256;
-  ensure_canonical(env, (hipStream_t)stream);
+  if (!ensure_canonical(env, (hipStream_t)stream, "w2a_get_state")) return W2A_ERR_STATE;
   hipLaunchKernelGGL(k_get_state, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, env->st, env->n, env->tb.Y, env->tb.n_samples, *view);
   HIP_TRY(hipGetLastError());
   end_call(env, (hipStream_t)stream);
@@ -823,55 +845,14 @@ int w2a_query(w2a_env *env, int what) {
   }
 }
 
-// largest budget the state buffer holds: the current episodes' (stepc.a) and the sticky ones (cold.z, -1 = unset)
-__global__ void k_budget_scan(StateArrays st, int64_t n, int32_t *out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t b = 0;
-  if (i < n) b = max((int32_t)st.stepc[i].a, (int32_t)st.cold[i].z);
-  for (int off = 32; off; off >>= 1) b = max(b, __shfl_xor(b, off));
-  if ((threadIdx.x & 63) == 0 && b > 0) atomicMax(out, b);
-}
-
 int w2a_invalidate(w2a_env *env, void *stream) {
   if (!env) return fail(W2A_ERR_ARG, "w2a_invalidate: NULL handle");
   hipStream_t s = (hipStream_t)stream;
-  {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-      return fail(W2A_ERR_STATE, "w2a_invalidate: the stream is recording a hipGraph (the call waits for the stream and "
-                                 "reads a value back)");
-    (void)hipGetLastError();
-  }
-  // What was known about budgets described another buffer, and the restored one may hold budgets -- sticky ones too --
-  // that no later reset argument will ever mention. The handle reads them itself: a rare call (checkpoint restore), so it
-  // may wait for `stream` -- the stream the caller wrote the buffer on -- and for nothing else (found by
-  // tools/sequence_fuzz.py, seed 99 sequence 77: a caller's bound stated after a later w2a_reset covered the new budgets
-  // only, a restored sticky budget of 65 721 then reached the 16-bit packed form)
-  int32_t *d_max = reinterpret_cast<int32_t *>(const_cast<int32_t *>(env->slot_obs)) + ROWF + 1;  // header scratch word 33
-  int32_t h_max = 0;
-  hipError_t e = hipMemsetAsync(d_max, 0, sizeof(int32_t), s);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_budget_scan, dim3((unsigned)((env->n + 255) / 256)), dim3(256), 0, s, env->st, env->n, d_max);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  // whatever happened above, the handle no longer trusts anything it derived from the old buffer
+  REFUSE_WHILE_CAPTURING("w2a_invalidate", s);
+  // nothing the handle derived from the old buffer is trusted; the restored budgets need no looking at (the packed kernel
+  // serves any budget: until round 5 this call scanned the buffer for its largest one and waited for the stream)
   bk_invalidate(env->bk);
-  if (e != hipSuccess) {
-    end_call(env, s);
-    return fail(W2A_ERR_HIP, "w2a_invalidate: scanning the restored buffer failed (budgets stay unknown: the packed "
-                             "form is off until w2a_set_budget_bound): %s", hipGetErrorString(e));
-  }
-  // restored budgets below zero are clamped by the reset kernels the same way (draw_episode: b < 0 -> 0)
-  bk_set_budget_bound(env->bk, (int64_t)(h_max > 0 ? h_max : 0));  // the first statement after bk_invalidate: taken as covering everything
   end_call(env, s);
-  return W2A_OK;
-}
-
-int w2a_set_budget_bound(w2a_env *env, int64_t bound) {
-  if (!env) return fail(W2A_ERR_ARG, "w2a_set_budget_bound: NULL handle");
-  bk_set_budget_bound(env->bk, bound);
   return W2A_OK;
 }
 

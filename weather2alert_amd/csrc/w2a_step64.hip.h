@@ -358,7 +358,7 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
                       make_uint4(pack_d0(0, 0, 0, 0, 0), pack_d1(0, ep.ndays, 0), __float_as_uint(0.0f), (uint32_t)ep.budget));
         if (PACKED) {  // the mirror's words of the new episode, over the ones phase C has just written (k_pack_state's packing)
           a.st.pk_hot[e] = make_uint2(pk_pack_hot(0u, 0u, 0u, 0u), __float_as_uint(0.0f));
-          a.st.pk_c[e] = make_uint2(((uint32_t)ep.budget & 0xFFFFu) | (W_COL(ep.ep_w) << 16),
+          a.st.pk_c[e] = make_uint2(pk_budget16((uint32_t)ep.budget) | (W_COL(ep.ep_w) << 16),
                                     (ep.ep_row & 0x3FFFFFu) | (W_SAMPLE(ep.ep_w) << 22));
         }
         if (WRITE_OBS) {
@@ -400,6 +400,10 @@ __device__ __forceinline__ void s64_load_packed(const StepArgs &a, uint32_t e, u
   h.b = pack_d1(PK_HIST(ph.x), (uint32_t)a.uni_nd, PK_FIN(ph.x));
   h.c = ph.y;
   c.a = pc.x & 0xFFFFu;
+  // budgets the 16-bit field cannot hold (w2a_common.hip.h, pk_budget16): the lane reads the canonical word, which every
+  // reset path writes and nothing changes while an episode runs -- a rare divergent 4-B load (env.py:167-178: a budget
+  // keyword of any size, a sticky centred budget that has walked upwards)
+  if (c.a == PK_BUDGET_ESCAPE) c.a = a.st.stepc[e].a;
   c.b = pc.y & 0x3FFFFFu;
   c.c = PACK_W(pc.x >> 16, pc.y >> 22);
   act = load_action(a, e);
@@ -489,7 +493,7 @@ __global__ void k_pack_state(StateArrays st, int64_t n) {
   const u3 h = st.hot3[i];
   const u3 c = st.stepc[i];
   st.pk_hot[i] = make_uint2(pk_pack_hot(D0_USED(h.a), D0_STREAK(h.a), D1_HIST(h.b), D1_FIN(h.b)), h.c);
-  st.pk_c[i] = make_uint2((c.a & 0xFFFFu) | (W_COL(c.c) << 16), (c.b & 0x3FFFFFu) | (W_SAMPLE(c.c) << 22));
+  st.pk_c[i] = make_uint2(pk_budget16(c.a) | (W_COL(c.c) << 16), (c.b & 0x3FFFFFu) | (W_SAMPLE(c.c) << 22));
   if ((i & 63) == 0) st.pk_day[i >> 6] = D0_T(h.a);
 }
 __global__ void k_unpack_state(StateArrays st, int64_t n, int32_t n_days) {

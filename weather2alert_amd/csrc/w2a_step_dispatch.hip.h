@@ -36,12 +36,11 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
   // packed variant from the mirror's per-tile day word), and no conversion between the two forms of the state is ever
   // recorded -- the recorded kernel's form stays the handle's primary form from then on (w2a_bookkeeping.h: bk_step,
   // graph_canon / graph_packed, bk_end_call).
-  bool capturing = false;
-  {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
-    else (void)hipGetLastError();
-  }
+  const bool capturing = stream_is_capturing(s);
+  if (capturing && (flags & W2A_STEP_NO_CAPTURE))
+    return fail(W2A_ERR_STATE, "w2a_step: the stream is recording a hipGraph, but this loop's episode boundaries are driven "
+                               "from the host (W2A_STEP_NO_CAPTURE): a reset between two steps cannot be recorded. Let the "
+                               "step kernel restart finished envs itself (W2A_STEP_AUTORESET; HeatAlertVecEnv(lockstep=False))");
   // measured on MI355X (profiles/r02/nsweep.log): below ~128 K envs the 4-lanes-per-env kernel wins (more, shorter
   // waves hide the two memory hops better: 5.0 vs 6.2 us at 65 536 envs), from there on the 64-envs-per-wave one
   const bool wide = (given || (flags & W2A_STEP_WIDE) || env->n >= W2A_S64_MIN_ENVS) && !(flags & W2A_STEP_CLASSIC);

@@ -86,8 +86,11 @@ class HeatAlertVecEnv(_VectorEnvBase):
                          16-B state there too). None (default): True when the tables allow it; falls back to
                          False by itself after a masked reset.
                          hipGraphs: step() neither synchronises nor allocates and reads the day from device memory;
-                         step once eagerly, then capture (torch.cuda.graph). The library keeps the form of the state the
-                         recorded steps work on current from then on (include/w2a.h, w2a_state_bytes).
+                         step once eagerly, then capture (torch.cuda.graph, or record_steps() below, which also reads the
+                         status word behind every replay). Needs lockstep=False or autoreset="disabled": a loop whose
+                         episode boundaries the host drives (the default in lock step: it counts days and launches the
+                         reset) cannot be recorded, and step() raises instead of recording it. The library keeps the form
+                         of the state the recorded steps work on current from then on (include/w2a.h, w2a_state_bytes).
     faithful / fixes     faithful=True (default) reproduces every reference quirk -- all parity
                          claims refer to this mode. ``fixes`` opts into individual corrections (faithful=False =
                          all of them): "alert_2wks" (Q1: the agent's 14-day count feeds the reward), "lag" (Q3:
@@ -312,7 +315,12 @@ class HeatAlertVecEnv(_VectorEnvBase):
             raise ValueError("reward_mode='posterior_mean' cannot run with the in-kernel autoreset (batches that left "
                              "lock step); use autoreset='disabled' or whole-batch resets")
         self._pm = self.reward_mode == "posterior_mean"
+        # episode boundaries driven from this class (a counted reset launch, a pending restart, NumPy draws on the host): such
+        # a loop cannot be recorded into a hipGraph -- w2a_step then refuses to record instead of baking a reset into a
+        # fixed position of the graph, or none at all (W2A_STEP_NO_CAPTURE; the query costs nothing extra)
+        host_driven = self._host_auto or self._host_next or (self.autoreset == "same_step" and not self._dev_auto)
         self._step_flags = ((0 if self.write_obs else _ffi.STEP_NO_OBS) |
+                            (_ffi.STEP_NO_CAPTURE if host_driven else 0) |
                             (_ffi.STEP_REWARD_GIVEN if self._pm else 0) |
                             (_ffi.STEP_CLASSIC if self.step_kernel == "classic" else 0) |
                             (_ffi.STEP_WIDE if self.step_kernel == "wide" else 0) |
@@ -371,7 +379,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
         out = C.c_int32(0)
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.w2a_read_status(self._h, C.byref(out), self._stream()), "w2a_read_status")
-        bits = out.value
+        return self._raise_for_status(out.value)
+
+    @property
+    def status_word(self) -> torch.Tensor:
+        """The device status word (int32 [1], W2A_ST_* bits, sticky until check_status() clears it): what a loop that
+        must not synchronise -- a replayed hipGraph -- copies out or asserts on."""
+        return self._status
+
+    @staticmethod
+    def _raise_for_status(bits: int) -> int:
         if bits & _ffi.ST_BAD_EPISODE:
             raise KeyError("reset: an episode tuple is out of range or has no data "
                            "(reference: KeyError at env.py:127 / ValueError at env.py:121)")
@@ -379,9 +396,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
             raise ValueError("step: actions must be 0 or 1 (action_space = Discrete(2))")
         if bits & _ffi.ST_STALE_GRAPH:
             raise RuntimeError("a replayed hipGraph holds step() calls on the packed lock-step form of this env's state, "
-                               "which could not be kept current (a masked reset, injected budgets or a restored checkpoint "
-                               "since the capture): those replayed steps did nothing. Reset the whole batch (or capture "
-                               "again) before replaying (include/w2a.h, w2a_state_bytes)")
+                               "which could not be kept current (a masked reset or a restored checkpoint since the "
+                               "capture took the batch out of lock step): those replayed steps did nothing. Reset the "
+                               "whole batch (or capture again) before replaying (include/w2a.h, w2a_state_bytes)")
         return bits
 
     def state(self) -> dict[str, torch.Tensor]:
@@ -415,6 +432,9 @@ class HeatAlertVecEnv(_VectorEnvBase):
                      "lockstep": self._lockstep, "reset_cfg": self._reset_cfg, "last_opts": dict(self._last_opts),
                      "needs_reset": self._needs_reset, "pending_reset": self._pending_reset, "info_location": list(getattr(self, "_info_location", [])),
                      "num_envs": self.num_envs, "env_gid0": self.env_gid0,
+                     # format of "state": w2a_state_bytes grew with ABI 17 (the mirror's day words); the canonical part
+                     # at its front (header, cold, hot3, stepc) is what a restore needs
+                     "abi_version": _ffi.ABI_VERSION, "state_bytes": int(self._state.numel()),
                      # pm_kernel="auto" measures; a resumed run must compute rewards with the same kernel to stay
                      # bit-exact with the run it continues (the kernels agree to ~1e-7, not to the last bit)
                      "pm_kernel_choice": self.pm_kernel_choice},
@@ -425,7 +445,20 @@ class HeatAlertVecEnv(_VectorEnvBase):
         if h["num_envs"] != self.num_envs or h["env_gid0"] != self.env_gid0:
             raise ValueError("state_dict belongs to a different env batch (num_envs / env_gid0 differ)")
         hdr = self._state[:256].clone()  # slot map written by w2a_create for THIS handle
-        self._state.copy_(sd["state"])
+        src = sd["state"]
+        if src.numel() == self._state.numel():
+            self._state.copy_(src)
+        else:
+            # a checkpoint of another build of the library (the lock-step mirror behind the canonical words changed size):
+            # the canonical part -- header, cold 16 B, hot3 12 B, stepc 12 B per env, each array on a 256-B boundary -- has
+            # had the same layout in every ABI version; w2a_invalidate rebuilds everything derived from it
+            a256 = lambda x: (x + 255) & ~255  # noqa: E731
+            canon = 256 + a256(16 * self.num_envs) + 2 * a256(12 * self.num_envs)
+            if src.numel() < canon or self._state.numel() < canon:
+                raise ValueError(f"state_dict['state'] holds {src.numel()} bytes (written by ABI {h.get('abi_version', '<= 17')}); "
+                                 f"this build (ABI {_ffi.ABI_VERSION}) needs at least the {canon} canonical bytes of "
+                                 f"{self.num_envs} envs: not a checkpoint of this env batch")
+            self._state[:canon].copy_(src[:canon])
         self._state[:256].copy_(hdr)
         # the state buffer changed behind the library: it forgets what it derived and scans the restored buffer for its
         # largest budget, sticky ones included (waits for this stream -- the one the copy above ran on -- and no other)
@@ -517,10 +550,6 @@ class HeatAlertVecEnv(_VectorEnvBase):
                                            None if mask_t is None else mask_t.data_ptr(), obs_ptr, self._stream()),
                        "w2a_reset")
         self._keep = (t, tb, mask_t)  # keep inputs alive until the async launch has consumed them
-        # the budgets went over in device memory: tell the library their maximum (it holds budgets in 16 bits while the
-        # batch is in lock step and cannot see device values)
-        _ffi.check(self._lib.w2a_set_budget_bound(self._h, int(max(int(bud[sel].max()) if sel.any() else 0, 0))),
-                   "w2a_set_budget_bound")
         self._regroup()
 
     def _per_env(self, v, i):
@@ -712,6 +741,16 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 self._reset_numpy_parity(None, self._last_opts, d, torch.as_tensor(d.astype(np.uint8),
                                          device=self.device), self._obs_ptr)
         return self._obs, self._reward, done, self._truncated, _LazyInfo(self)
+
+    def record_steps(self, one_day, days: int, warmup: bool = True):
+        """Record `days` calls of one_day() -- a policy on device tensors + self.step(actions) -- into a hipGraph and
+        return a weather2alert_amd.graph.RecordedSteps: .replay() launches the block and reads the device status word
+        BEHIND every replay (asynchronously: replay k checks what replay k-1 left), so a block that could not run -- the
+        mirror of a packed lock-step batch marked stale by a masked reset or a restored checkpoint, W2A_ST_STALE_GRAPH --
+        or bad actions raise at the next replay instead of training on frozen observations."""
+        from .graph import RecordedSteps
+
+        return RecordedSteps(self, one_day, days, warmup)
 
     # ------------------------------------------------------------------ rollout
     def rollout(self, policy: dict, n_steps: int | None = None, alert_mask: bool = False) -> dict:
