@@ -83,6 +83,10 @@ def parse(argv=None):
     p.add_argument("--only-extras", default=None, metavar="NAME[,NAME...]",
                    help="single-GPU run: of the reported extras only these (always_alert, sorted, posterior_mean, rollout, "
                         "configs4, configs1)")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="do not start the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE on tools/pmc_probe.py) that "
+                        "measure roofline.traffic in this very run; the figure is then replayed from profiles/traffic_latest.json "
+                        "when the kernel sources still hash to the recorded value")
     p.add_argument("--no-calibration", action="store_true",
                    help="skip the in-process copy-rate / access-pattern probe that follows the timed region")
     p.add_argument("--seed", type=int, default=0)
@@ -97,6 +101,9 @@ def parse(argv=None):
                    help="unpacked = auto without the packed lock-step mirror of the per-env state (A/B)")
     p.add_argument("--launch-timeout", type=float, default=1500.0,
                    help="--gpus N self-launcher: seconds after which still-running ranks are terminated")
+    p.add_argument("--tamper", default=None, choices=["return", "obs"],
+                   help="(test hook) after the timed region, falsify one finished episode's return / one observation value "
+                        "of the timed batch: the parity leg must then fail and the exit code be 5")
     p.add_argument("--fail-rank", type=int, default=-1,
                    help="(launcher test hook) this rank exits with code 3 right after start-up")
     p.add_argument("--sweep", default=None, metavar="N1,N2,...",
@@ -583,6 +590,63 @@ def sharded_workload(wl, args, rank, world, device, torch, HeatAlertVecEnv, synt
                     "of the N = 1 line"}
 
 
+# ------------------------------------------------------------------------------------------ fabric traffic, live
+def live_traffic(workload: str, n: int, no_obs: bool, step_kernel: str, episode_order: str, variant: str, timeout_s: int = 240):
+    """roofline.traffic measured in THIS run: two child processes `rocprofv3 --pmc <counter> --kernel-trace -- python3
+    tools/pmc_probe.py ...` (FETCH_SIZE, then WRITE_SIZE: separate passes, MI355X_MICROARCH.md HBM section), started after
+    every timing of this process is over and its env is closed -- a counter pass cannot run inside a process that is
+    already up. The probe steps the same workload on the same library and, in the same process, runs a 1 GiB copy whose
+    byte count is known: FETCH_SIZE is calibrated on it (gfx950 reports half the bytes of 16-B-per-lane reads), WRITE_SIZE
+    is exact. Returns (entry like those of profiles/traffic_latest.json, None) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process is itself running under rocprofv3: no nested counter passes"
+    roc = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(roc):
+        return None, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="w2a_pmc_", dir=os.environ.get("TMPDIR") if os.path.isdir(os.environ.get("TMPDIR", "")) else "/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    res, per_pass_s = {}, {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, ctr)
+            cmd = [roc, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", "python3",
+                   os.path.join(ROOT, "tools", "pmc_probe.py"), "--workload", workload, "--num-envs", str(n), "--steps", "16",
+                   "--step-kernel", step_kernel, "--episode-order", episode_order] + (["--no-obs"] if no_obs else [])
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+            per_pass_s[ctr] = round(time.perf_counter() - t0, 1)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}"
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr:
+                        key = (row["Dispatch_Id"], row["Kernel_Name"])
+                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            step = [v for (_, k), v in per.items() if (variant + "<") in k]
+            copy = [v for (_, k), v in per.items() if "copyBuffer" in k and v > 1e5]
+            if not step or not copy:
+                return None, f"the {ctr} pass saw {len(step)} {variant} launches and {len(copy)} calibration copies"
+            res[ctr] = (sum(step) / len(step), sum(copy) / len(copy), len(step))
+        gib = float(1 << 30)
+        rd_corr, wr_corr = gib / (res["FETCH_SIZE"][1] * 1024), gib / (res["WRITE_SIZE"][1] * 1024)
+        rd, wr = res["FETCH_SIZE"][0] * 1024 * rd_corr, res["WRITE_SIZE"][0] * 1024 * wr_corr
+        return {"bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                "read_correction": rd_corr, "write_correction": wr_corr, "launches_averaged": res["FETCH_SIZE"][2],
+                "pass_seconds": per_pass_s,
+                "profile": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of tools/pmc_probe.py in this run"}, None
+    except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
+        return None, repr(e)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------------ parity of the timed batch
 def parity_check(env, sd, ct, pool, act_log, torch, extra_steps=8, max_sample=4096):
     """Does the batch that was just TIMED hold what the reference would hold? (cpu-baseline leg: the oracle is the checker,
@@ -762,11 +826,33 @@ def extras(out, args, torch, HeatAlertVecEnv, synth, tables, dt, ct, device, n, 
         timed_steps(e3, pool, 10, torch)
         kms, _ = timed_steps(e3, pool, 130, torch)
         us = kms * 1e3 / 130
-        out["sorted_episode_order"] = {
-            "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
-            "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
-                    "row after each reset"}
+        res = {"kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s (kernel)",
+               "roofline_frac": cb["total"] * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "note": "opt-in episode_order='sorted': same episode multiset, env indices relabelled by table "
+                       "row after each reset"}
+        # END TO END: whole episodes by the wall clock -- every step() call, the reset kernel after each terminal step and,
+        # in sorted mode, the relabelling that follows it (counting sort by coefficient row, state permutation, first
+        # observations) -- for the sorted order and, in the same way on a fresh env, for the default iid order
+        def whole_episodes(e, episodes=3):
+            for _ in range(T - (e._steps_in_episode % T)):  # to the next episode boundary, untimed
+                e.step(pool[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(episodes * T):
+                e.step(pool[i & 15])
+            torch.cuda.synchronize()
+            return n * episodes * T / (time.perf_counter() - t0)
+
+        res["value_end_to_end"] = whole_episodes(e3)
+        e3.close()
+        e3 = HeatAlertVecEnv(n, tables=dt, device=device, similar_climate_counties=augment,
+                             write_obs=not args.no_obs, step_kernel=args.step_kernel)
+        e3.reset(seed=args.seed)
+        res["iid_value_end_to_end"] = whole_episodes(e3)
+        res["end_to_end_gain"] = res["value_end_to_end"] / res["iid_value_end_to_end"]
+        res["end_to_end_note"] = ("env-steps/s by the wall clock over 3 whole episodes, resets and (sorted) the per-episode "
+                                  "relabelling included; iid = the default order measured the same way in the same process")
+        out["sorted_episode_order"] = res
         e3.close()
 
     def posterior_mean():
@@ -1199,6 +1285,10 @@ def main():
     # parity of the very batch that was timed, against the oracle (rank 0; cpu-baseline leg, outside every timed region)
     parity = None
     if rank == 0 and not args.no_parity:
+        if args.tamper == "return":
+            env._final_return[n - 1] += 0.01
+        elif args.tamper == "obs":
+            env._obs[0, 3] += 1.0
         try:
             parity = parity_check(env, sd, ct, pool, act_log, torch)
         except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
@@ -1211,6 +1301,7 @@ def main():
             c4_sharded = sharded_workload("configs4", args, rank, world, device, torch, HeatAlertVecEnv, synth, tables, wdist)
         except Exception as e:  # noqa: BLE001  (reported, never loses the headline line)
             c4_sharded = {"error": repr(e)}
+    rc = 0
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         per_launch_s = (kernel_us * 1e-6) if kernel_us else dev_ms * 1e-3 / args.steps
@@ -1232,6 +1323,17 @@ def main():
                 traffic = ent
             elif ent is not None:
                 traffic_note = "profiles/traffic_latest.json was collected on other kernel sources: not reported"
+        traffic_live = False
+        if world == 1 and not args.no_live_traffic and not args.graph:
+            # measured in this very run (every timing above is over; the env is closed first so that the probe has the GPU's
+            # memory to itself): the replayed figure above is only the fallback
+            env.close()
+            live, why = live_traffic(args.workload, n, args.no_obs, args.step_kernel, args.episode_order, variant)
+            if live is not None:
+                traffic, traffic_live, traffic_note = dict(live, src_sha=src_sha), True, None
+            else:
+                traffic_note = f"live counter passes not available ({why})" + ("; replayed from profiles/traffic_latest.json"
+                                                                                 if traffic is not None else "")
         # the memory side's measured rate for this access pattern without any env logic (static reference from
         # profiles/, 1 048 576 envs): kernel time / probe time says how close the kernel is to what the chip delivers
         probe = None
@@ -1282,7 +1384,8 @@ def main():
                          # (a 1 GiB fill writes at ~6.9 TB/s on this chip, a float4 copy moves 6.29 TB/s)
                          "fabric_gbs": None if traffic is None else traffic["bytes_per_launch"] / per_launch_s / 1e9,
                          "traffic_source": None if traffic is None else
-                         {k: traffic.get(k) for k in ("read_bytes_per_launch", "write_bytes_per_launch",
+                         {k: traffic.get(k) for k in ("read_bytes_per_launch", "write_bytes_per_launch", "read_correction",
+                                                      "launches_averaged", "pass_seconds",
                                                       "kernel_avg_us", "src_sha", "commit", "profile")},
                          "traffic_note": traffic_note, "kernel_src_sha": src_sha,
                          "probe_ceiling": probe,
@@ -1294,9 +1397,13 @@ def main():
                          if calib and calib.get("probe_us") else None,
                          "frac_of_copy_rate_this_box": (achieved / calib["copy_gbs"]) if calib and calib.get("copy_gbs") else None,
                          "calibration": None if not calib else {k: v for k, v in calib.items() if k in ("source", "error")},
+                         "traffic_live": traffic_live,
                          "traffic_provenance": None if traffic is None else
-                         "REPLAYED from profiles/traffic_latest.json (rocprofv3 --pmc passes of the same command on the "
-                         "same kernel sources, src_sha checked; counters cannot be read inside this process)",
+                         ("LIVE: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_probe.py: the same "
+                          "workload on the same library + a 1 GiB calibration copy) started by this run after its timed "
+                          "region" if traffic_live else
+                          "REPLAYED from profiles/traffic_latest.json (rocprofv3 --pmc passes of the same command on the "
+                          "same kernel sources, src_sha checked)"),
                          "frac_of_measured_copy_bw": achieved / 6290.0,
                          "frac_with_unpacked_161B_model": compulsory_bytes(ct.n_obs, not args.no_obs)["total"] * n
                          / per_launch_s / 1e9 / HBM_PEAK_GBS,
@@ -1314,6 +1421,17 @@ def main():
             "status_bits": status, "mean_final_return": mean_ret, "setup_s": t_setup,
             "parity": parity,
         }
+        # the driver's record keeps the scalars of `config` and `roofline` (of other objects only the key name): what says
+        # that the timed batch holds what the reference would hold is mirrored there
+        psum = {"parity_ok": None if parity is None else bool(parity.get("ok")),
+                "parity_max_abs_reward_err": None if parity is None else parity.get("max_abs_reward_err"),
+                "parity_sampled_envs": None if parity is None else parity.get("sampled"),
+                "parity_env_steps_replayed_per_env": None if parity is None else parity.get("env_steps_replayed_per_env"),
+                "parity_ints_and_obs_exact": None if parity is None else
+                bool(parity.get("ints_exact")) and parity.get("obs_exact") is not False,
+                "status_bits": status}
+        out["roofline"].update(psum)
+        out["config"].update(psum)
         if c4_sharded is not None:
             out["configs4_sharded"] = c4_sharded
         if world == 1 and args.episode_order == "iid" and not args.graph and not args.no_extras:
@@ -1331,12 +1449,25 @@ def main():
                     out["cpu_baseline"]["multi_core"] = {"error": repr(e)}
             except Exception as e:  # noqa: BLE001  (the headline JSON line must survive a failing baseline leg)
                 out["cpu_baseline"] = {"error": repr(e)}
+        so = out.get("sorted_episode_order")
+        if isinstance(so, dict) and "value_end_to_end" in so:  # (scalars the driver's record keeps)
+            out["roofline"].update(sorted_order_kernel_us=so["kernel_us"], sorted_order_value_end_to_end=so["value_end_to_end"],
+                                   iid_value_end_to_end=so["iid_value_end_to_end"])
         print(json.dumps(out), flush=True)
+        # the exit code says whether the numbers above count: parity of the timed batch held and no kernel flagged anything
+        if parity is not None and not parity.get("ok", False) and "skipped" not in parity:
+            print(f"bench.py: PARITY FAILED on the timed batch: {parity.get('notes') or parity.get('error')}", file=sys.stderr, flush=True)
+            rc = 5
+        elif status != 0 or (parity is not None and parity.get("status_bits")):
+            print(f"bench.py: a kernel raised status bits ({status}, parity leg {parity and parity.get('status_bits')})",
+                  file=sys.stderr, flush=True)
+            rc = 6
     env.close()
+    rc = int(wdist.max_over_ranks(float(rc), device))  # every rank leaves with rank 0's verdict (the others hold 0)
     wdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

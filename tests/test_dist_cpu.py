@@ -208,3 +208,33 @@ def test_bench_defaults_follow_baseline_configs():
     assert 1 <= cpus["usable"] <= cpus["os_cpu_count"] and cpus["usable"] <= cpus["affinity"]
     assert cpus["cgroup_quota_cpus"] is None or cpus["usable"] <= max(1, int(cpus["cgroup_quota_cpus"] + 0.5))
     assert isinstance(b.cpu_model(), str) and b.cpu_model()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_first_contact_children_on_cpu(tmp_path):
+    """tools/rccl_first_contact.py -- the children of the multi-GPU RCCL test (tests/test_rccl_gpu.py) -- with --stub over gloo:
+    its launcher (fresh interpreters, polled), the rendezvous on 127.0.0.1, the overlapped return gather per episode and the
+    result file, on 2 and on 4 ranks, against its own single-process mode; and a launch whose group cannot form fails instead
+    of hanging."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "rccl_first_contact.py")
+    for world in (2, 4):
+        two, one = str(tmp_path / f"w{world}.pt"), str(tmp_path / f"s{world}.pt")
+        r = subprocess.run([sys.executable, tool, "--launch", str(world), "--backend", "gloo", "--stub", "--num-envs", "3000", "--out", two],
+                           capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([sys.executable, tool, "--single", str(world), "--stub", "--num-envs", "3000", "--out", one],
+                           capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, b = torch.load(two), torch.load(one)
+        assert a["ranks_seen"] == world and b["ranks_seen"] == 1 and a["num_envs_total"] == b["num_envs_total"] == 3000 * world
+        assert len(a["returns"]) == 3 and all(torch.equal(x, y) for x, y in zip(a["returns"], b["returns"]))
+    # without a GPU the real children must fail loudly (no CPU fallback), and the launcher must report it and return
+    r = subprocess.run([sys.executable, tool, "--launch", "2", "--backend", "gloo", "--num-envs", "64", "--out", str(tmp_path / "x.pt"),
+                        "--timeout", "120"], capture_output=True, text=True, timeout=200)
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a ROCm GPU" in r.stderr
+

@@ -395,7 +395,6 @@ class Runner:
                 zero = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
                 _ffi.check(e._lib.w2a_reset_device_rng(e._h, *e._reset_cfg, 1, zero.data_ptr(), e._obs_ptr, e._stream()),
                            "w2a_reset_device_rng")
-                m._note_cfg(m.reset_cfg)
                 m._note_launch_reset(masked=True)
             torch.cuda.synchronize()
             if m.pm:

@@ -347,9 +347,16 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
   if (AUTORESET) {
     // env.py:162-181 for the envs that finished today: next episode from the device RNG (draw_episode, the k_reset /
     // k_step<AUTORESET> code), its state words over the ones phase C has just written, its day-0 row as the returned
-    // observation (the pass flush left the finished env's row alone)
+    // observation (the pass flush left the finished env's row alone).
+    // The first observation is written the way phase B reads rows: 8 lanes = one 128-B row, 8 envs per round, descriptors
+    // through LDS. Until round 5 every restarting LANE fetched its own row (8 x 16 B from 64 different lines per
+    // instruction) and stored its 29 floats one by one at a 116-B stride: on the day a lock-step batch restarts -- every
+    // lane of every wave -- that cost ~600 us per 1 M envs against 56 us for k_reset, i.e. 2.5-4 us per step averaged over
+    // an episode (profiles/r03/exp_autoreset_modes.log: 39.8 vs 35.9 us; profiles/r05/bench_graph51.log: 36.6 vs 34.1).
     const bool rs = valid && (a.next_step ? restart_in : done);
-    if (__any(rs)) {
+    const unsigned long long rs_mask = __ballot(rs);
+    if (rs_mask) {  // wave-uniform
+      uint2 ds = make_uint2(0xFFFFFFFFu, 0u);
       if (rs) {
         const uint4 cold = load_cold(a.st, e);
         const Episode ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + e), cold.w + 1, (int32_t)cold.z);
@@ -361,20 +368,28 @@ __device__ __forceinline__ void s64_tile(const StepArgs &a, S64WaveT<FIXES> &sw,
           a.st.pk_c[e] = make_uint2(pk_budget16((uint32_t)ep.budget) | (W_COL(ep.ep_w) << 16),
                                     (ep.ep_row & 0x3FFFFFu) | (W_SAMPLE(ep.ep_w) << 22));
         }
-        if (WRITE_OBS) {
-          float *row = reinterpret_cast<float *>(a.obs) + (size_t)e * n_obs;
-          const float4 *xr = a.tb.X + (size_t)ep.ep_row * (ROWF / 4);  // day 0
-#pragma unroll
-          for (int qd = 0; qd < ROWF / 4; ++qd) {
-            float4 v = xr[qd];
-            if (qd == RT_QUAD) v = make_float4(0.0f, 0.0f, (float)ep.budget, 0.0f);
-            if (FIXES && (fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && qd == (a.tb.slot_hist2w >> 2))
+        ds = make_uint2(ep.ep_row * (ROWF / 4), (uint32_t)ep.budget);  // float4 index of the day-0 row, the budget
+      }
+      if (WRITE_OBS) {
+        sw.desc[lane] = ds;  // (phase B is over: the descriptor slots are free)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int r = 0; r < S64_ENVS / 8; ++r) {
+          if (!((rs_mask >> (r * 8)) & 0xFFull)) continue;  // wave-uniform: no env of this round restarts
+          const int j = r * 8 + g;
+          const uint2 dj = sw.desc[j];
+          if (dj.x != 0xFFFFFFFFu) {
+            float4 v = a.tb.X[dj.x + p];  // day 0
+            if (p == RT_QUAD) v = make_float4(0.0f, 0.0f, (float)(int32_t)dj.y, 0.0f);
+            if (FIXES && (fx & W2A_FIX_ALERTS_2WKS) && a.tb.slot_hist2w >= 0 && p == (a.tb.slot_hist2w >> 2))
               set_comp4(v, a.tb.slot_hist2w & 3, 0.0f);  // the agent's (empty) history replaces the column
-            const int4 sq = reinterpret_cast<const int4 *>(a.slot_obs)[qd];
-            if (sq.x >= 0) row[sq.x] = v.x;
-            if (sq.y >= 0) row[sq.y] = v.y;
-            if (sq.z >= 0) row[sq.z] = v.z;
-            if (sq.w >= 0) row[sq.w] = v.w;
+            float *row = reinterpret_cast<float *>(a.obs) + (size_t)(wave_env0 + j) * n_obs;
+            if (so.x >= 0) row[so.x] = v.x;
+            if (so.y >= 0) row[so.y] = v.y;
+            if (so.z >= 0) row[so.z] = v.z;
+            if (so.w >= 0) row[so.w] = v.w;
           }
         }
       }
