@@ -225,6 +225,17 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
  * workspace: caller-owned, w2a_sort_workspace_bytes(num_envs) bytes, 256-B aligned. */
 size_t w2a_sort_workspace_bytes(int64_t num_envs);
 int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
+/* The same relabelling fused into the whole-batch device-RNG reset that precedes it (what episode_order="sorted" does once
+ * per episode): w2a_reset_device_rng + w2a_sort_episodes + w2a_observe in three launches and no moved record. Pass 1 draws
+ * every env's next episode and keeps only its sort key -- (coefficient row, feature row) as one 32-bit word -- with the env's
+ * sticky budget and episode number; a stable radix sort of (key, env index); pass 2 is k_reset with "index e receives the
+ * episode env src[e] draws" (same global id, sticky budget and episode number as that env's own draw: the result is bit
+ * for bit that of the three calls above) and writes state and first observations (obs nullable) in place.
+ * Arguments as w2a_reset_device_rng without a mask; workspace as w2a_sort_episodes. Returns 1 (nothing done) when the key
+ * does not fit 32 bits (S * n_samples * S_w * Y > 2^32): the caller runs the three calls instead. */
+int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                                int sample_budget_mode, int sticky, int restart_episodes, float *obs, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* reward_mode = "posterior_mean" (the legacy env's eval mode, _deprecated/env.py:332-342: `posterior_indices =
  * np.arange(n_posterior_samples) if eval_mode`, `np.mean([_get_reward(i, ...)])`, on today's reward form

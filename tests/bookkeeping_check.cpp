@@ -199,10 +199,13 @@ static void check_invariants(World &w) {
 // ---------------------------------------------------------------- entry points (bookkeeping side of w2a_kernels.hip)
 static void end_call(World &w) { StubDev d{w}; bk_end_call(w.bk, d); }
 
-static void api_reset_device(World &w, bool masked, unsigned sel, bool launch_fails = false) {  // w2a_reset_device_rng / w2a_reset + launch_reset
+// sorted: w2a_reset_device_rng_sorted (whole batch; the new episodes land in coefficient-row order, and its k_reset pass does
+// not do the rank atomics of an attached order workspace)
+static void api_reset_device(World &w, bool masked, unsigned sel, bool launch_fails = false, bool sorted = false) {  // w2a_reset_device_rng / w2a_reset + launch_reset
   StubDev d{w};
   const W2aBook before = w.bk;
-  bk_reset(w.bk, d, false, masked);
+  if (sorted) bk_reset_sorted(w.bk, d);
+  else bk_reset(w.bk, d, false, masked);
   if (launch_fails) {
     bk_reset_rollback(w.bk, before, false, masked);
     note(w, "    (the launch failed: rolled back)");
@@ -213,7 +216,7 @@ static void api_reset_device(World &w, bool masked, unsigned sel, bool launch_fa
   for (int i = 0; i < w.ne; ++i)
     if (!masked || ((sel >> i) & 1u)) new_episode(w, i);
   w.epoch = ++w.clock;
-  if (w.bk.hist_valid) {  // launch_reset: k_reset also counts rows / ranks envs -- those it selects
+  if (w.bk.hist_valid && !sorted) {  // launch_reset: k_reset also counts rows / ranks envs -- those it selects
     REQUIRE(w, !masked, "stale grouping: a masked k_reset left row counts of the selected envs only");
     w.hist_for = w.epoch;
   }
@@ -378,7 +381,7 @@ struct Op {
   // step
   bool wide = false, autoreset = false, next = false, given = false, unpacked = false, capturing = false, fails = false;
   // resets (w2a_reset_device_rng and w2a_reset look the same to the bookkeeping)
-  bool masked = false; unsigned sel = 0;
+  bool masked = false; unsigned sel = 0; bool sorted = false;
   // rollout
   int32_t n_steps = 1; bool fixes = false; int prep = 0;  // prep: 0 nothing, 1 new order, 2 new order + tile list
   int shape = 0, graph = 0;
@@ -388,7 +391,7 @@ static std::string describe(const Op &o) {
   switch (o.kind) {
     case OP_STEP: snprintf(b, sizeof b, "step(wide %d autoreset %d next %d given %d unpacked %d%s%s)", o.wide, o.autoreset, o.next, o.given,
                            o.unpacked, o.capturing ? " CAPTURING" : "", o.fails ? " LAUNCH FAILS" : ""); break;
-    case OP_RESET: snprintf(b, sizeof b, "reset(masked %d sel %u%s)", o.masked, o.sel, o.fails ? " LAUNCH FAILS" : ""); break;
+    case OP_RESET: snprintf(b, sizeof b, "reset(masked %d sel %u%s%s)", o.masked, o.sel, o.sorted ? " SORTED" : "", o.fails ? " LAUNCH FAILS" : ""); break;
     case OP_ROLLOUT: snprintf(b, sizeof b, "rollout(%d, fixes %d, prep %d)", o.n_steps, o.fixes, o.prep); break;
     case OP_GET_STATE: return "get_state";
     case OP_SORT: return "sort";
@@ -413,7 +416,7 @@ static void apply(World &w, const Op &o) {
       if (o.given) api_pm_reward(w);
       api_step(w, o.wide, o.autoreset && w.has_autoreset, o.next, o.given, o.unpacked, o.capturing, o.fails);
       break;
-    case OP_RESET: api_reset_device(w, o.masked, o.sel, o.fails); break;
+    case OP_RESET: api_reset_device(w, o.masked, o.sel, o.fails, o.sorted); break;
     case OP_ROLLOUT:
       if (o.prep >= 1) { api_rollout_order(w); if (o.prep >= 2) api_rm_prepare(w); }
       api_rollout(w, o.n_steps, o.fixes);
@@ -458,6 +461,7 @@ static void run_sequence(uint64_t seed, int n_ops) {
     } else if (u < 54) {
       o.kind = OP_RESET; o.masked = rng.coin(40);
       o.sel = rng.coin(20) ? all : (unsigned)rng.below(all + 1); o.fails = rng.coin(4);
+      if (!o.masked && rng.coin(25)) o.sorted = true;
     } else if (u < 62) {
       o.kind = OP_ROLLOUT; o.n_steps = (int32_t)(1 + rng.below(9)); o.fixes = rng.coin(15);
       o.prep = rng.coin(60) ? (rng.coin(80) ? 2 : 1) : 0;
@@ -513,6 +517,7 @@ static std::vector<Op> all_ops() {
     Op o; o.kind = OP_RESET; o.masked = m > 0; o.sel = m == 1 ? 1u : (m == 2 ? 3u : 7u);
     v.push_back(o);
     o.fails = true; v.push_back(o);  // ... and the same reset with a k_reset launch that fails
+    if (m == 0) { o.sorted = true; v.push_back(o); o.fails = false; v.push_back(o); }  // w2a_reset_device_rng_sorted, failing and not
   }
   { Op o; o.kind = OP_OBSERVE; o.fails = true; v.push_back(o); }
   for (int32_t n : {1, 2, 9})

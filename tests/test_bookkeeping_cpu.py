@@ -76,6 +76,8 @@ MUTANTS = [
     ("a restore keeps the row counts", "  b.hist_valid = 0;\n  b.poisoned = 0;", "  b.poisoned = 0;"),
     ("a restored buffer is taken to be still poisoned (round 5, GPU fuzz seed 505 sequence 357)",
      "  b.poisoned = 0;  // the caller's copy covered the mirror's day words too", "  //"),
+    ("the fused sorted reset claims row counts its k_reset pass never took", "  bk_reset(b, d, false, false);\n  b.hist_valid = 0;\n",
+     "  bk_reset(b, d, false, false);\n"),
     ("another order workspace inherits the row counts", "  b.has_order_ws = 1; b.hist_valid = 0;\n", "  b.has_order_ws = 1;\n"),
     ("a failed full reset claims the canonical words it never wrote",
      "  const bool unpacked = (masked || observe_only) && !before.canon_valid;", "  const bool unpacked = !before.canon_valid;"),

@@ -780,6 +780,41 @@ def test_sorted_episode_order_is_a_relabelling(dev):
     assert srt.check_status() == 0
     iid.close()
     srt.close()
+    # The relabelling is FUSED into the reset since round 6 (w2a_reset_device_rng_sorted: draw keys, one stable 32-bit radix
+    # sort, k_reset that gives every index the episode of its source env; no record is moved). Bit for bit round 5's
+    # three-call sequence (reset, 64-bit sort + state permutation, observe) -- through sticky sampled budgets, whose chain
+    # follows the RECORD, an explicit re-seed in the middle of an episode, and three lock-step autoresets
+    for n2 in (n, 131072 + 9):  # (the larger batch steps on the packed form)
+        fused = HeatAlertVecEnv(n2, episode_order="sorted", sorted_reset="fused", **kw)
+        relab = HeatAlertVecEnv(n2, episode_order="sorted", sorted_reset="relabel", **kw)
+        g = torch.Generator(device=dev).manual_seed(2)
+        acts = [(torch.rand(n2, device=dev, generator=g) < 0.3).to(torch.int32) for _ in range(5)]
+
+        def both_equal(where):
+            sa, sb = fused.state(), relab.state()
+            for kk in sa:
+                assert torch.equal(sa[kk], sb[kk]), (where, kk)
+            assert torch.equal(fused._obs, relab._obs) and torch.equal(fused._final_return, relab._final_return), where
+
+        opts = {"sample_budget": True, "sample_budget_type": "centered"}
+        fused.reset(seed=6, options=opts)
+        relab.reset(seed=6, options=opts)
+        both_equal("first reset")
+        st0 = fused.state()
+        kk = ((st0["coef_col"].long() << 12 | st0["sample"].long()) << 32 | (st0["county_w"].long() * ct.Y + st0["year_i"].long()))
+        assert bool((kk[1:] >= kk[:-1]).all())
+        for t in range(40):
+            fused.step(acts[t % 5]); relab.step(acts[t % 5])
+        fused.reset(seed=7, options=opts)  # re-seed mid-episode: the episode counters restart, the sticky budgets stay
+        relab.reset(seed=7, options=opts)
+        both_equal("re-seed")
+        for t in range(3 * 153 + 11):
+            fused.step(acts[t % 5]); relab.step(acts[t % 5])
+            if t % 153 in (0, 151, 152):
+                both_equal(f"step {t}")
+        assert int(fused.state()["episode_no"].min()) == 3 and fused.check_status() == 0 and relab.check_status() == 0
+        fused.close()
+        relab.close()
 
 
 def test_ragged_episode_lengths_and_missing_pairs(dev):

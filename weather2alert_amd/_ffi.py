@@ -21,7 +21,7 @@ BUDGET_FIXED, BUDGET_LESS_THAN, BUDGET_CENTERED = 0, 1, 2
 SYMBOLS = [
     "w2a_abi_version", "w2a_last_error", "w2a_state_bytes", "w2a_create", "w2a_destroy", "w2a_reset",
     "w2a_reset_device_rng", "w2a_set_autoreset", "w2a_step", "w2a_get_state", "w2a_read_status",
-    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order_attach", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
+    "w2a_sort_workspace_bytes", "w2a_sort_episodes", "w2a_reset_device_rng_sorted", "w2a_observe", "w2a_rollout", "w2a_rollout_order_workspace_bytes", "w2a_rollout_order_attach", "w2a_rollout_order", "w2a_rollout_posterior_mean", "w2a_policy_actions", "w2a_set_semantics",
     "w2a_group_workspace_bytes", "w2a_group_by_column", "w2a_posterior_mean_reward", "w2a_set_posterior_kernel", "w2a_invalidate", "w2a_query", "w2a_rollout_mfma_workspace_bytes", "w2a_rollout_mfma_prepare",
 ]
 Q_LOCKSTEP_DAY, Q_PACKED_ELIGIBLE, Q_PACKED_CURRENT, Q_CANONICAL_CURRENT, Q_LAST_ROLLOUT_KERNEL, Q_LAST_STEP_KERNEL, Q_LOCKSTEP = 0, 1, 2, 3, 4, 5, 6
@@ -110,6 +110,8 @@ def load(build_if_missing: bool = True):
     lib.w2a_sort_workspace_bytes.argtypes = [i64]
     lib.w2a_sort_episodes.restype = C.c_int
     lib.w2a_sort_episodes.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.w2a_reset_device_rng_sorted.restype = C.c_int
+    lib.w2a_reset_device_rng_sorted.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]
     lib.w2a_group_workspace_bytes.restype = C.c_size_t
     lib.w2a_group_workspace_bytes.argtypes = [i64, C.c_int32, C.c_int32]
     lib.w2a_group_by_column.restype = C.c_int

@@ -125,6 +125,14 @@ static inline void bk_reset(W2aBook &b, Dev &d, bool observe_only, bool masked) 
   b.hist_valid = (!masked && b.has_order_ws && !b.graph_autoreset) ? 1 : 0;
 }
 
+// w2a_reset_device_rng_sorted: a whole-batch reset whose new episodes land on the env indices in coefficient-row order. To the
+// flags it is a whole-batch reset -- except that its second pass does not do the rank atomics of an attached order workspace
+template <class Dev>
+static inline void bk_reset_sorted(W2aBook &b, Dev &d) {
+  bk_reset(b, d, false, false);
+  b.hist_valid = 0;
+}
+
 // The k_reset launch bk_reset prepared did not happen: the state is what it was, except that the conversion a masked
 // reset / w2a_observe on the packed form asked for did run and left both forms current. Derived structures are dropped.
 static inline void bk_reset_rollback(W2aBook &b, const W2aBook &before, bool observe_only, bool masked) {

@@ -375,11 +375,25 @@ static size_t cub_sort_bytes(int64_t n) {
   return b;
 }
 
+static size_t cub_sort32_bytes(int64_t n) {
+  size_t b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+  return b;
+}
+// what w2a_reset_device_rng_sorted lays out in the same workspace: keys in / out, indices in / out, {sticky, episode} pairs
+static size_t sorted_reset_bytes(int64_t num_envs) {
+  const size_t n = (size_t)num_envs;
+  return 4 * align256(4 * n) + align256(8 * n) + align256(cub_sort32_bytes(num_envs));
+}
+
 size_t w2a_sort_workspace_bytes(int64_t num_envs) {
   if (num_envs <= 0 || num_envs > (1ll << 27)) return 0;
   size_t n = (size_t)num_envs;
-  return align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 +
-         align256(cub_sort_bytes(num_envs));
+  const size_t relabel = align256(8 * n) * 2 + align256(4 * n) * 2 + align256(16 * n) + align256(12 * n) * 2 +
+                         align256(cub_sort_bytes(num_envs));
+  const size_t fused = sorted_reset_bytes(num_envs);
+  return relabel > fused ? relabel : fused;
 }
 
 int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
@@ -413,6 +427,57 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   HIP_TRY(hipMemcpyAsync(env->st.cold, cold_t, 16 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.hot3, hot_t, 12 * n, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(env->st.stepc, stepc_t, 12 * n, hipMemcpyDeviceToDevice, s));
+  end_call(env, s);
+  return W2A_OK;
+}
+
+int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
+                                int sample_budget_mode, int sticky, int restart_episodes, float *obs, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_reset_device_rng_sorted: NULL argument");
+  if (workspace_bytes < w2a_sort_workspace_bytes(env->n)) return fail(W2A_ERR_STATE, "w2a_reset_device_rng_sorted: workspace too small");
+  if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_reset_device_rng_sorted: workspace must be 256-B aligned");
+  if (obs && ((uintptr_t)obs & 15)) return fail(W2A_ERR_ARG, "w2a_reset_device_rng_sorted: obs must be 16-B aligned");
+  ResetArgs a;
+  memset(&a, 0, sizeof(a));
+  const int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
+  if (rc) return rc;
+  // (coefficient row, feature row) as one 32-bit key: 167 M values on the reference's tables. Larger tables take the
+  // general path (w2a_reset_device_rng + w2a_sort_episodes + w2a_observe): the caller is told with return value 1
+  const uint64_t key_space = (uint64_t)env->tb.S * env->tb.n_samples * ((uint64_t)env->tb.S_w * env->tb.Y);
+  if (key_space > 0xFFFFFFFFull) return 1;
+  REFUSE_WHILE_CAPTURING("w2a_reset_device_rng_sorted", stream);
+  int end_bit = 1;
+  while (end_bit < 32 && (key_space - 1) >> end_bit) ++end_bit;
+  const size_t n = (size_t)env->n;
+  char *p = (char *)workspace;
+  uint32_t *k_in = (uint32_t *)p;  p += align256(4 * n);
+  uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
+  uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
+  uint32_t *i_out = (uint32_t *)p; p += align256(4 * n);
+  uint2 *zw = (uint2 *)p;          p += align256(8 * n);
+  size_t cub_bytes = cub_sort32_bytes(env->n);
+  hipStream_t s = (hipStream_t)stream;
+  // pass 1 reads `cold` only (written by every reset path, never stale in either form of the step state)
+  hipLaunchKernelGGL(k_reset_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->tb, a.rc, env->st, env->n, env->gid0,
+                     restart_episodes ? 1 : 0, k_in, i_in, zw);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, end_bit, s));  // stable
+  const W2aBook before = env->bk;
+  {
+    HipDev d{env, s};
+    bk_reset_sorted(env->bk, d);
+  }
+  a.obs = obs; a.from_tuples = 3; a.src_idx = i_out; a.src_zw = zw;
+  a.tb = env->tb; a.slot_obs = env->slot_obs; a.st = env->st;
+  a.status = env->status; a.n = env->n; a.gid0 = env->gid0;
+  hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, s, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    bk_reset_rollback(env->bk, before, false, false);
+    end_call(env, s);
+    return fail(W2A_ERR_HIP, "w2a_reset_device_rng_sorted: launch failed: %s", hipGetErrorString(e));
+  }
   end_call(env, s);
   return W2A_OK;
 }

@@ -17,7 +17,10 @@ struct ResetArgs {
   int64_t n;
   int64_t gid0;
   ResetCfg rc;
-  int32_t from_tuples;  // 0: device RNG draw, 1: caller's tuples, 2: observe only (state untouched)
+  int32_t from_tuples;  // 0: device RNG draw, 1: caller's tuples, 2: observe only (state untouched), 3: device RNG draw of
+                        // the env src_idx[e] (w2a_reset_device_rng_sorted: the new episodes land in coefficient-row order)
+  const uint32_t *src_idx;  // [n] which env's draw index e receives (a permutation)
+  const uint2 *src_zw;      // [n] by SOURCE env: {sticky budget, episode number of the new episode} (k_reset_keys)
   int32_t restart;      // device RNG draw: 1 = the per-env episode counter restarts at 0 (explicit re-seed)
   // whole-batch resets of a handle with an attached order workspace (w2a_rollout_order_attach; both NULL otherwise): envs
   // per feature row (zeroed by the caller before the launch) and each env's position inside its row -- the first pass
@@ -62,6 +65,14 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     ep.ndays = (uint32_t)nd;
     ep.budget = a.budget ? a.budget[e] : a.tb.B0[ep.ep_row];
     ep.sticky = (int32_t)cold.z;
+  } else if (a.from_tuples == 3) {
+    // the episode env `src` draws -- its global id, its sticky budget, its episode number: exactly what k_reset draws for
+    // it in the iid order -- lands on index e: the relabelling of episode_order="sorted" without moving any record
+    const uint32_t src = a.src_idx[e];
+    const uint2 zw = a.src_zw[src];
+    ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + src), zw.y, (int32_t)zw.x);
+    bad = ep.bad;
+    cold.w = zw.y - 1u;  // (stored below as cold.w + 1)
   } else {
     // an explicit re-seed restarts the per-env episode counter, so equal seeds give equal episodes
     // (env.py:143-145 re-creates the Generator); autoresets keep counting up from there
@@ -89,6 +100,21 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     if (a.order_cnt) a.order_rank[e] = atomicAdd(&a.order_cnt[ep.ep_row], 1u);
   }
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
+}
+
+// w2a_reset_device_rng_sorted, first pass: the key of the episode every env is about to draw -- coefficient row (column,
+// draw) major, feature row minor, as ONE 32-bit word -- with the env's index, and what the second pass needs of the env's
+// old record once other indices' records have been overwritten: its sticky budget and the new episode's number.
+__global__ void k_reset_keys(DevTables tb, ResetCfg rc, StateArrays st, int64_t n, int64_t gid0, int32_t restart,
+                             uint32_t *keys, uint32_t *idx, uint2 *zw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 cold = st.cold[i];
+  const uint32_t epno = restart ? 0u : cold.w + 1u;
+  const Episode ep = draw_episode(tb, rc, (uint64_t)(gid0 + i), epno, (int32_t)cold.z);
+  keys[i] = (W_COL(ep.ep_w) * (uint32_t)tb.n_samples + W_SAMPLE(ep.ep_w)) * (uint32_t)(tb.S_w * tb.Y) + ep.ep_row;
+  idx[i] = (uint32_t)i;
+  zw[i] = make_uint2(cold.z, epno);
 }
 
 __global__ void k_init_state(StateArrays st, int64_t n) {

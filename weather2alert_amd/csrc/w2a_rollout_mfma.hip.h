@@ -26,7 +26,8 @@
 #define RM_WAVES 1  // waves (= tiles) per workgroup: no workgroup-level synchronisation is used, and single-wave workgroups
                     // leave the dispatcher the finest grain (measured 0.87 / 0.88 / 0.90 ms per episode for 1 / 2 / 4)
 #endif
-#define RM_ZSTRIDE 33  // floats per env of the logit-part image: 16 days x 2 heads + 1 pad (lane = env reads, bank-conflict free)
+#define RM_ZSTRIDE 34  // floats per env of the logit-part image: 16 days x 2 heads + 2 pad (8-B aligned pairs; lane = env reads of a
+                       // {baseline, effectiveness} pair are bank-conflict free)
 
 struct RmArgs {
   RolloutArgs r;
@@ -53,6 +54,10 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
   int ew = 0;
   if (m > 0.0f) (void)frexpf(m, &ew);
   if (ew > W2A_PI8_EW_MAX) atomicOr(&rowflag[r >> 1], 1u);
+  // a coefficient on slot 27 (the agent's 14-day count: none in the faithful semantics, Q1 -- alert_2wks is an appended
+  // observation key, not a reward feature) is honoured by the exact path, so that the common path carries three run-time
+  // terms per head instead of four
+  if (W[r * ROWF + 27] != 0.0f) atomicOr(&rowflag[r >> 1], 1u);
   const float s = ldexpf(1.0f, 30 - ew);
   uint32_t planes[4][8];
 #pragma unroll
@@ -89,14 +94,13 @@ __global__ void k_rm_tiles(const uint32_t *start, const uint32_t *tile_start, in
 // SIMD resident the day loop is bound by the latency of its own instruction chain, and those wave-uniform choices
 // otherwise cost a dozen scalar branches per day.
 #ifndef RM_MIN_WAVES
-#define RM_MIN_WAVES 3  // waves per SIMD the kernel is compiled for (168 VGPRs; 2: 0.99 ms, 4: 1.04 ms with spills)
+#define RM_MIN_WAVES 3  // waves per SIMD the kernel is compiled for (<= 168 VGPRs: 156-168 by policy kind, no spills)
 #endif
 template <int KIND, bool MASKS>
 __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(const RmArgs ra) {
   const RolloutArgs &a = ra.r;
   __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
   __shared__ float sZ[RM_WAVES][64][RM_ZSTRIDE];                                      // logit parts [env][day * 2 + head]
-  __shared__ float sSc[RM_WAVES][64][2];                                              // row scales [env][head]
   __shared__ float sDay[RM_WAVES][16][2];  // per day of the chunk: gate flag (slot 30), the threshold policy's feature
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,14 +130,14 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
   const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
   const float *Wf = reinterpret_cast<const float *>(a.tb.W) + (size_t)wrow * (2 * ROWF);
-  const bool exact = ra.rowflag[wrow] != 0u;  // this env's coefficient row is outside the fixed-point range
-  // the three run-time coefficients of both heads (slots 24, 25, 26; slot 27 has none in the faithful semantics, Q1 --
-  // kept anyway so that a coefficient there is honoured)
-  const double wl_b = Wf[24], ws_b = Wf[25], wr_b = Wf[26], wa_b = Wf[27];
-  const double wl_e = Wf[ROWF + 24], ws_e = Wf[ROWF + 25], wr_e = Wf[ROWF + 26], wa_e = Wf[ROWF + 27];
-  sSc[wave][lane][0] = ra.wscale[(size_t)wrow * 2];
-  sSc[wave][lane][1] = ra.wscale[(size_t)wrow * 2 + 1];
-  // A operands: row tile m, lane (c16, q) holds 16 slots of one plane of env 16 m + c16 (its coefficient digits)
+  const bool exact = ra.rowflag[wrow] != 0u;  // this env's coefficient row is outside the fixed-point range (or uses slot 27)
+  const bool any_exact = __any(exact) != 0;   // wave-uniform: the common case never enters the exact path's control flow
+  // the env's two row scales 2^(ew - 20): powers of two, applied by the env's own lane in the day loop (exact), so that the
+  // matrix-core section needs no per-row scale (until round 6 it read 32 of them from LDS per chunk, and the compiler kept
+  // them -- loop invariants -- in 32 + 32 registers through the whole launch: the kernel's spills)
+  const float sc_b = ra.wscale[(size_t)wrow * 2], sc_e = ra.wscale[(size_t)wrow * 2 + 1];
+  // A operands: row tile m, lane (c16, q) holds 16 slots of one plane of env 16 m + c16 (its coefficient digits): 64
+  // registers for the whole launch
   pi8_v4i P[4][2], Q[4][2];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -150,19 +154,27 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   constexpr int32_t kind = KIND;
   float ret = 0.0f;
   int32_t alerts = 0, over = 0;
-  uint32_t mask_word = 0, mask_idx = 0xFFFFFFFFu;
-  uint32_t att_word = 0, att_idx = 0xFFFFFFFFu;
+  uint32_t mask_word = 0, att_word = 0;
   float snap = 0.0f;
   bool snapped = false;
+  // Lock step (the handle's bookkeeping; else k_rollout64 serves the call): every env of the batch is on the same day of an
+  // episode of the one length there is, finished or not together. So the day, the number of days this call runs, "today
+  // is the terminal day" and the word of the day bitmaps are WAVE-UNIFORM: they live in scalar registers, and the day loop
+  // has a fixed trip count and no per-lane control flow (round 6; until then every day re-derived them per lane and the
+  // compiler kept three nested exec-mask conditions alive through the loop: ~35 scalar mask instructions and 8 branches
+  // per day beside ~75 vector ones).
+  const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
+  const uint32_t nd_u = __builtin_amdgcn_readfirstlane(ndays);
+  const bool fin_u = __builtin_amdgcn_readfirstlane((uint32_t)fin) != 0u;
+  int total = fin_u ? 0 : min(a.n_steps, (int)(nd_u - t_first));  // days this call runs
+  const bool ends = !fin_u && total == (int)(nd_u - t_first);     // ... the terminal one among them
+  uint32_t tu = t_first;                                          // today
   // threshold policy: the lagging observation (row of day t - 1, Q6) is carried from day to day; obs_lag = 0 reads today's
   const int pol_quad = kind == W2A_POLICY_THRESHOLD ? (a.pol_slot >> 2) : -1, pol_comp = a.pol_slot & 3;
   float feat = 0.0f;
-  if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t > 0)
-    feat = Xf[((size_t)((t - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
-  bool active = !fin && valid;
-  const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);  // lock step: every env of the batch is on this day
-  int steps_left = a.n_steps;
-  for (uint32_t c0 = t_first; steps_left > 0 && __any(active); c0 += 16) {
+  if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t_first > 0)
+    feat = Xf[((size_t)((t_first - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
+  for (uint32_t c0 = t_first; total > 0; c0 += 16) {
     // ---- feature digits of days c0 .. c0 + 15 of this (county, year): lane = (day, two slot groups)
     {
       const int j = lane >> 2, g0 = (lane & 3) * 2;
@@ -205,22 +217,25 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (16 * m >= count) continue;  // wave-uniform
+      float z0[4];  // head 0's logit parts of the four accumulator rows, kept until head 1's are there: one 8-B store per row
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const pi8_v4i zero = {0, 0, 0, 0};
-        pi8_v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[0], zero, 0, 0, 0);
-        pi8_v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[1], zero, 0, 0, 0);
-        pi8_v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[2], zero, 0, 0, 0);
-        pi8_v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P[m][h], B[3], zero, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Q[m][h], B[0], a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Q[m][h], B[1], a3, 0, 0, 0);
+        const pi8_v4i Pm = P[m][h], Qm = Q[m][h];
+        pi8_v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[0], zero, 0, 0, 0);
+        pi8_v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[1], zero, 0, 0, 0);
+        pi8_v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[2], zero, 0, 0, 0);
+        pi8_v4i a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Pm, B[3], zero, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[0], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qm, B[1], a3, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // accumulator row 4 q + j of the row tile = env, column c16 = day
           const int er = 16 * m + 4 * q + j;
-          const float sc = sSc[wave][er][h];
           const float u = (float)(a0[j] * 256 + a1[j]);
           const float v = (float)(a2[j] * 256 + a3[j]);
-          sZ[wave][er][c16 * 2 + h] = fmaf(v, sc * 1.52587890625e-05f, u * sc);
+          const float z = fmaf(v, 1.52587890625e-05f, u);  // x the row's scale (a power of two: exact) in the day loop
+          if (h == 0) z0[j] = z;
+          else *reinterpret_cast<float2 *>(&sZ[wave][er][c16 * 2]) = make_float2(z0[j], z);
         }
       }
     }
@@ -228,85 +243,84 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ)
-    const int chunk = min(16, steps_left);
-    for (int dd = 0; dd < chunk; ++dd) {
-      if (!__any(active)) break;
-      const float today = sDay[wave][dd][1], gate = sDay[wave][dd][0];  // lock step: t = c0 + dd in every live lane
-      const int32_t act = policy_action(kind, a.pol, pstream, t, budget - (int32_t)used,
-                                        (a.pol.obs_lag && t > 0) ? feat : today);
+    // the three run-time coefficients of both heads (slots 24, 25, 26) as doubles: fetched per chunk (two 16-B loads from
+    // the env's coefficient rows, cache hits) so that their 12 registers are not held through the matrix-core section
+    const float *wrt = Wf + 24;
+    asm volatile("" : "+v"(wrt));
+    const float4 rtb = *reinterpret_cast<const float4 *>(wrt), rte = *reinterpret_cast<const float4 *>(wrt + ROWF);
+    const double wl_b = rtb.x, ws_b = rtb.y, wr_b = rtb.z, wl_e = rte.x, ws_e = rte.y, wr_e = rte.z;
+    const int chunk = min(16, total);
+    for (int dd = 0; dd < chunk; ++dd, ++tu) {
+      const float today = sDay[wave][dd][1], gate = sDay[wave][dd][0];
+      const int32_t act = policy_action(kind, a.pol, pstream, tu, budget - (int32_t)used,
+                                        (a.pol.obs_lag && tu > 0) ? feat : today);
       const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
       const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
       const uint32_t used2 = used + actual;
       const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
-      const uint32_t day_row = t * rows_per_day + frow;
-      const double f_lag = (t > 0) ? (double)actual : 0.0, f_streak = (double)streak;
-      const double f_rem = (double)(budget - (int32_t)used2), f_a2w = (double)__popc(hist2);
-      double zb, ze;
-      if (exact) {  // plain fp64 dot products for a coefficient row outside the fixed-point range
-        zb = 0.0; ze = 0.0;
-        const float *xr = Xf + (size_t)day_row * ROWF;
-        for (int k = 0; k < ROWF; ++k) {
-          if (k >= 24 && k <= 27) continue;
-          const double xk = (double)xr[k];
-          zb = fma(xk, (double)Wf[k], zb);
-          ze = fma(xk, (double)Wf[ROWF + k], ze);
+      const double f_lag = (double)(tu > 0 ? actual : 0u), f_streak = (double)streak;
+      const double f_rem = (double)(budget - (int32_t)used2);
+      const float2 zt = *reinterpret_cast<const float2 *>(&sZ[wave][lane][dd * 2]);
+      double zb = (double)(zt.x * sc_b), ze = (double)(zt.y * sc_e);
+      if (any_exact) {   // wave-uniform; rare
+        if (exact) {     // plain fp64 dot products for a coefficient row outside the fixed-point range (or with a slot-27 term)
+          zb = 0.0; ze = 0.0;
+          const float4 *xr = a.tb.X + (size_t)(tu * rows_per_day + frow) * (ROWF / 4);
+          const float4 *wr4 = reinterpret_cast<const float4 *>(Wf);
+          // one quad of slots per trip, NOT unrolled: unrolled, this rare path held 16 float4 loads in flight and set the
+          // register allocation of the whole kernel (the source of its spills until round 6)
+#pragma unroll 1
+          for (int qd = 0; qd < ROWF / 4; ++qd) {
+            if (qd == RT_QUAD) continue;  // slots 24..27: the run-time fields, added below
+            const float4 xv = xr[qd], wb = wr4[qd], we = wr4[ROWF / 4 + qd];
+            zb = fma((double)xv.x, (double)wb.x, zb); ze = fma((double)xv.x, (double)we.x, ze);
+            zb = fma((double)xv.y, (double)wb.y, zb); ze = fma((double)xv.y, (double)we.y, ze);
+            zb = fma((double)xv.z, (double)wb.z, zb); ze = fma((double)xv.z, (double)we.z, ze);
+            zb = fma((double)xv.w, (double)wb.w, zb); ze = fma((double)xv.w, (double)we.w, ze);
+          }
+          const double f_a2w = (double)__popc(hist2);
+          zb = fma(f_a2w, (double)Wf[27], zb);
+          ze = fma(f_a2w, (double)Wf[ROWF + 27], ze);
         }
-      } else {
-        zb = (double)sZ[wave][lane][dd * 2];
-        ze = (double)sZ[wave][lane][dd * 2 + 1];
       }
-      zb = fma(f_lag, wl_b, zb); zb = fma(f_streak, ws_b, zb); zb = fma(f_rem, wr_b, zb); zb = fma(f_a2w, wa_b, zb);
-      ze = fma(f_lag, wl_e, ze); ze = fma(f_streak, ws_e, ze); ze = fma(f_rem, wr_e, ze); ze = fma(f_a2w, wa_e, ze);
+      zb = fma(f_lag, wl_b, zb); zb = fma(f_streak, ws_b, zb); zb = fma(f_rem, wr_b, zb);
+      ze = fma(f_lag, wl_e, ze); ze = fma(f_streak, ws_e, ze); ze = fma(f_rem, wr_e, ze);
       if (!(gate > 0.5f)) ze = -__builtin_inf();
       const float r = reward_from_logits(zb, ze, actual);
-      if (active) {
-        const bool done = (t + 1 >= ndays);
-        ret += r;
-        ret_total += r;
-        alerts += (int32_t)actual;
-        over += (act == 1 && atb_s) ? 1 : 0;
-        if (MASKS && a.alert_mask && actual) {
-          const uint32_t wi = t >> 5;
-          if (wi != mask_idx) {
-            if (mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
-              a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
-            mask_idx = wi;
-            mask_word = 0;
+      const bool done = tu + 1 >= nd_u;  // wave-uniform: the last day this call runs, if it runs to the end
+      ret += r;
+      ret_total += r;
+      alerts += (int32_t)actual;
+      over += (act == 1 && atb_s) ? 1 : 0;
+      if (MASKS) {
+        mask_word |= actual << (tu & 31u);
+        att_word |= (uint32_t)(act == 1) << (tu & 31u);
+        if ((tu & 31u) == 31u || dd + 1 == total) {  // wave-uniform: the bitmap word of these 32 days is complete (or the call ends)
+          const uint32_t wi = tu >> 5;
+          if (valid && wi < (uint32_t)a.mask_words) {
+            if (a.alert_mask && mask_word) a.alert_mask[(size_t)e * a.mask_words + wi] |= mask_word;
+            if (a.attempt_mask && att_word) a.attempt_mask[(size_t)e * a.mask_words + wi] |= att_word;
           }
-          mask_word |= 1u << (t & 31);
+          mask_word = 0; att_word = 0;
         }
-        if (MASKS && a.attempt_mask && act == 1) {
-          const uint32_t wi = t >> 5;
-          if (wi != att_idx) {
-            if (att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
-              a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
-            att_idx = wi;
-            att_word = 0;
-          }
-          att_word |= 1u << (t & 31);
-        }
-        if (MASKS && (done ? t : t + 1) + 2 == ndays) { snap = ret_total; snapped = true; }
-        used = used2; hist = hist2; last = actual; atb = atb_s;
-        if (!done) { streak = actual ? streak + 1 : 0; t = t + 1; }
-        else { fin = true; active = false; }
-        feat = today;
+        if ((done ? tu : tu + 1) + 2 == nd_u) { snap = ret_total; snapped = true; }
       }
+      used = used2; hist = hist2; last = actual; atb = atb_s;
+      if (!done) streak = actual ? streak + 1 : 0;  // (env.py:256-260: the terminal step leaves day and streak as they are)
+      feat = today;
     }
-    steps_left -= chunk;
+    total -= chunk;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // sXd / sZ are rewritten by the next chunk
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  if (!fin_u) { t = ends ? nd_u - 1u : tu; fin = ends; }
   if (valid) {
     store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
                                   __float_as_uint(ret_total), (uint32_t)budget));
     if (a.ret_out) a.ret_out[e] = ret;
     if (a.alerts_out) a.alerts_out[e] = alerts;
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
-    if (MASKS && a.alert_mask && mask_idx != 0xFFFFFFFFu && mask_idx < (uint32_t)a.mask_words)
-      a.alert_mask[(size_t)e * a.mask_words + mask_idx] |= mask_word;
-    if (MASKS && a.attempt_mask && att_idx != 0xFFFFFFFFu && att_idx < (uint32_t)a.mask_words)
-      a.attempt_mask[(size_t)e * a.mask_words + att_idx] |= att_word;
     if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
   }

@@ -634,10 +634,22 @@ class HeatAlertVecEnv(_VectorEnvBase):
         lib, st = self._lib, self._stream()
         srt = self.episode_order == "sorted"
         with torch.cuda.device(self.device):
-            _ffi.check(lib.w2a_reset_device_rng(self._h, *self._reset_cfg, int(restart), None if mask_t is None else
-                                                mask_t.data_ptr(), None if srt else obs_ptr, st),
-                       "w2a_reset_device_rng")
-            if srt:
+            if srt and self.kernel.sorted_reset == "fused":
+                # draw keys -> stable radix sort -> k_reset with "index e receives the episode env src[e] draws": the
+                # relabelling without moving a record (1 = the key does not fit 32 bits: the three calls below)
+                rc = lib.w2a_reset_device_rng_sorted(self._h, *self._reset_cfg, int(restart), obs_ptr, self._sort_ws.data_ptr(),
+                                                     self._sort_ws.numel(), st)
+                if rc not in (0, 1):
+                    _ffi.check(rc, "w2a_reset_device_rng_sorted")
+                srt = rc == 1
+                done = rc == 0
+            else:
+                done = False
+            if not done:
+                _ffi.check(lib.w2a_reset_device_rng(self._h, *self._reset_cfg, int(restart), None if mask_t is None else
+                                                    mask_t.data_ptr(), None if srt else obs_ptr, st),
+                           "w2a_reset_device_rng")
+            if srt and not done:
                 _ffi.check(lib.w2a_sort_episodes(self._h, self._sort_ws.data_ptr(), self._sort_ws.numel(), st),
                            "w2a_sort_episodes")
                 if obs_ptr is not None:

@@ -30,6 +30,10 @@ class KernelOptions:
     # env's own batch after the first reset and keeps the fastest -- a per-process choice unless the env is given
     # pm_sync_group=, which broadcasts the group's first rank's choice: a collective inside the first reset())
     pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "matrix_i8"
+    # episode_order="sorted": "fused" = w2a_reset_device_rng_sorted (draw keys, one stable 32-bit radix sort, k_reset that
+    # writes every index the episode of its source env: no record is moved); "relabel" = round 5's sequence
+    # w2a_reset_device_rng + w2a_sort_episodes (64-bit keys, state permutation, three copies) + w2a_observe. Bit-identical.
+    sorted_reset: Literal["fused", "relabel"] = "fused"
 
     def __post_init__(self):
         if self.step_kernel not in ("auto", "classic", "wide", "unpacked"):
@@ -41,6 +45,8 @@ class KernelOptions:
             raise ValueError(f"reward_path {self.reward_path!r}")
         if self.pm_kernel not in ("auto", "vector", "matrix", "matrix_i8"):
             raise ValueError(f"pm_kernel {self.pm_kernel!r}")
+        if self.sorted_reset not in ("fused", "relabel"):
+            raise ValueError(f"sorted_reset {self.sorted_reset!r}")
 
     @classmethod
     def names(cls) -> tuple:
