@@ -52,7 +52,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
     ep.ep_row = cold.x;
     ep.budget = (int32_t)hot.w;
     if (D0_T(hot.x) != 0) bad = 4;
-  } else if (a.from_tuples) {
+  } else if (a.from_tuples == 1) {
     int32_t cw = a.county_w[e], yi = a.year_i[e], cc = a.coef_col[e], sm = a.sample[e];
     if (cw < 0 || cw >= a.tb.S_w) { cw = 0; bad = 1; }
     if (yi < 0 || yi >= a.tb.Y) { yi = 0; bad = 1; }
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   } else if (a.from_tuples == 3) {
     // the episode env `src` draws -- its global id, its sticky budget, its episode number: exactly what k_reset draws for
     // it in the iid order -- lands on index e: the relabelling of episode_order="sorted" without moving any record
-    const uint32_t src = a.src_idx[e];
+    uint32_t src = a.src_idx[e];
+    if (src >= (uint32_t)a.n) { src = e; bad = 1; }  // (cannot happen with the sorted indices; never index past the workspace)
     const uint2 zw = a.src_zw[src];
     ep = draw_episode(a.tb, a.rc, (uint64_t)(a.gid0 + src), zw.y, (int32_t)zw.x);
     bad = ep.bad;
