@@ -245,11 +245,9 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
  *   w2a_group_by_column        after EVERY reset -- and after anything else that changes which episode an env index
  *                              holds: w2a_sort_episodes, a w2a_step with W2A_STEP_AUTORESET (both mark the grouping
  *                              stale, and w2a_posterior_mean_reward then refuses to run) --: sorts the env ids by coefficient column into `workspace`
- *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples, S_w * Y, T), 256-B
- *                              aligned, must stay alive while w2a_posterior_mean_reward is used) and writes a pre-scaled
- *                              fp64 copy of W there -- and, once per table (since ABI 18), the int8 digit planes of the
- *                              feature table itself (as large as X: 160 MB on the reference's tables), from which the
- *                              int8 matrix-core kernels take the table-sourced part of every env's row. W rows that give slot 28, 30 or 31 a coefficient are honoured (w2a_create
+ *                              (caller-owned, w2a_group_workspace_bytes(num_envs, S, n_samples), 256-B aligned, must
+ *                              stay alive while w2a_posterior_mean_reward is used) and writes a pre-scaled fp64 copy
+ *                              of W there. W rows that give slot 28, 30 or 31 a coefficient are honoured (w2a_create
  *                              scans for them once) at the price of a wider contraction;
  *   w2a_posterior_mean_reward  before w2a_step(..., W2A_STEP_REWARD_GIVEN) with the SAME actions: writes
  *                              reward [num_envs] f32 from the pre-step state. Same budget gate as the step
@@ -265,7 +263,7 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
  *                              (it is built on the vector form). */
 enum { W2A_PM_VECTOR = 0, W2A_PM_MATRIX_F64 = 1, W2A_PM_MATRIX_I8 = 2 };
 int w2a_set_posterior_kernel(w2a_env *env, int kernel);
-size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples, int64_t table_rows, int32_t T);
+size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples);
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtype, float *reward, void *stream);
 

@@ -16,7 +16,7 @@ int main(void) {
   if (w2a_abi_version() != W2A_ABI_VERSION) return 1;
   if (w2a_state_bytes(1000) < 256 + 40 * 1000 || w2a_state_bytes(1000) % 256) return 2;
   t.T = 153; t.S_w = 746; t.Y = 11; t.S = 746; t.n_samples = 100;
-  if (w2a_group_workspace_bytes(1000, 10, 10, 20, 153) < 4 * 4 * 1000 + 153 * 20 * 128 || w2a_group_workspace_bytes(0, 10, 10, 20, 153) != 0) return 3;
+  if (w2a_group_workspace_bytes(1000, 10, 10) < 4 * 4 * 1000 || w2a_group_workspace_bytes(0, 10, 10) != 0) return 3;
   if (w2a_create(&t, 8, 0, NULL, 0, NULL, &h) != W2A_ERR_ARG || h != NULL) return 4;
   if (!strstr(w2a_last_error(), "NULL")) return 5;
   if (w2a_step(NULL, NULL, W2A_ACT_I32, NULL, NULL, NULL, NULL, 0, NULL) != W2A_ERR_ARG) return 6;

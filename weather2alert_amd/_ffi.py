@@ -113,7 +113,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_reset_device_rng_sorted.restype = C.c_int
     lib.w2a_reset_device_rng_sorted.argtypes = [vp, u64, i32, C.c_int, i32, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]
     lib.w2a_group_workspace_bytes.restype = C.c_size_t
-    lib.w2a_group_workspace_bytes.argtypes = [i64, C.c_int32, C.c_int32, i64, C.c_int32]
+    lib.w2a_group_workspace_bytes.argtypes = [i64, C.c_int32, C.c_int32]
     lib.w2a_group_by_column.restype = C.c_int
     lib.w2a_group_by_column.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_posterior_mean_reward.restype = C.c_int

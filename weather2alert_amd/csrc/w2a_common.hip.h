@@ -195,8 +195,6 @@ struct w2a_env {
   const uint32_t *colflag;
   const float *xs;
   const void *xmax_ws;   // workspace whose slot maxima (once-per-table scan) are valid
-  const void *xd_ws;     // ... and whose digit planes of the feature table are built
-  const uint32_t *xd;
   // matrix-core rollout (w2a_rollout_mfma.hip.h): tile list by feature row + digit table of W, in its own workspace
   // order workspace (w2a_rollout_order_attach / w2a_rollout_order): envs per feature row, each env's rank inside its row,
   // first position and first 64-env tile of every row (rows + 1 entries each)

@@ -253,7 +253,7 @@ int w2a_create(const w2a_tables *t, int64_t num_envs, int64_t env_gid0, void *st
   h->order = nullptr;
   h->prep = nullptr;
   h->pm_kernel = W2A_PM_VECTOR;
-  h->xmax_ws = nullptr; h->xd_ws = nullptr; h->xd = nullptr;
+  h->xmax_ws = nullptr;
   h->order_ws = nullptr; h->order_cnt = h->order_rank = h->order_start = h->order_tile_start = nullptr; h->rm_ws = nullptr;
   for (int j = 0; j < ROWF; ++j) h->obs_slot_host[j] = j < t->n_obs ? t->obs_slot[j] : -1;
   hipError_t e1 = hipMemcpy(state, slot_obs, sizeof(slot_obs), hipMemcpyHostToDevice);
@@ -501,18 +501,15 @@ static size_t i8_bytes(int64_t n, int32_t S, int32_t n_samples) {
   return align256(16 * max_tiles_i8(n, S)) + 256 + align256(rows * ROWF * 4) + align256(rows * 4) + align256(4 * (size_t)S) + 3 * 256;
 }
 
-size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples, int64_t table_rows, int32_t T) {
-  if (num_envs <= 0 || num_envs > (1ll << 27) || S <= 0 || n_samples <= 0 || table_rows <= 0 || table_rows > 0x7FFFFFFFll || T <= 0)
-    return 0;
+size_t w2a_group_workspace_bytes(int64_t num_envs, int32_t S, int32_t n_samples) {
+  if (num_envs <= 0 || num_envs > (1ll << 27) || S <= 0 || n_samples <= 0) return 0;
   return align256(4 * (size_t)num_envs) * 4 + align256(16 * (size_t)num_envs) + wd_bytes(S, n_samples) +
-         tile_bytes(num_envs, S) + i8_bytes(num_envs, S, n_samples) + align256(cub_group_bytes(num_envs)) +
-         align256((size_t)T * (size_t)table_rows * ROWF * 4);  // the digit planes of the feature table: as large as X itself
+         tile_bytes(num_envs, S) + i8_bytes(num_envs, S, n_samples) + align256(cub_group_bytes(num_envs));
 }
 
 int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_group_by_column: NULL argument");
-  if (workspace_bytes < w2a_group_workspace_bytes(env->n, env->tb.S, env->tb.n_samples, (int64_t)env->tb.S_w * env->tb.Y, env->tb.T))
-    return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
+  if (workspace_bytes < w2a_group_workspace_bytes(env->n, env->tb.S, env->tb.n_samples)) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_group_by_column: workspace must be 256-B aligned");
   REFUSE_WHILE_CAPTURING("w2a_group_by_column", stream);
   const size_t n = (size_t)env->n;
@@ -537,7 +534,6 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   uint32_t *k_out = (uint32_t *)p; p += align256(4 * n);
   uint32_t *i_in = (uint32_t *)p;  p += align256(4 * n);
   size_t cub_bytes = cub_group_bytes(env->n);
-  uint32_t *xd = (uint32_t *)(p + align256(cub_bytes));  // behind the sort's scratch: digit planes of the feature table
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_group_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->st.stepc, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
@@ -571,13 +567,6 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   HIP_TRY(hipGetLastError());
   env->tiles_i8 = tiles_i8; env->n_tiles_i8 = n_tiles_i8; env->wq = wq; env->wscale = wscale; env->colflag = colflag;
   env->xs = xs;
-  if (env->xd_ws != workspace) {  // once per table and workspace (the table slots' scales do not depend on the episode)
-    const int64_t n_quads = (int64_t)env->tb.T * env->tb.S_w * env->tb.Y * (ROWF / 4);
-    hipLaunchKernelGGL(k_pi8_xd, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, env->tb.X, xs, n_quads, xd);
-    HIP_TRY(hipGetLastError());
-    env->xd_ws = workspace;
-  }
-  env->xd = xd;
   // fp64 copy of the coefficient rows, scaled by -log2(e), for the lane = env form of the reward kernel
   const int64_t w_count = (int64_t)env->tb.S * env->tb.n_samples * 2 * ROWF;
   hipLaunchKernelGGL(k_pm_wd, dim3((unsigned)((w_count + 255) / 256)), dim3(256), 0, s,
@@ -610,7 +599,7 @@ int w2a_posterior_mean_reward(w2a_env *env, const void *actions, int action_dtyp
   if (env->pm_kernel == W2A_PM_MATRIX_I8) {
     PmI8Args b;
     b.p = a; b.tiles = env->tiles_i8; b.n_tiles = env->n_tiles_i8; b.wq = env->wq; b.wscale = env->wscale;
-    b.colflag = env->colflag; b.xs = env->xs; b.xd = env->xd;
+    b.colflag = env->colflag; b.xs = env->xs;
     const unsigned grid = (unsigned)((max_tiles_i8(env->n, env->tb.S) + 7) / 8 * 8);
     hipLaunchKernelGGL(k_posterior_mean_i8, dim3(grid), dim3(PI8_THREADS), 0, (hipStream_t)stream, b);
   } else if (env->pm_kernel == W2A_PM_MATRIX_F64) {
@@ -747,9 +736,7 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
     hipLaunchKernelGGL(k_rm_wq, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, wq, wscale, rowflag);
     const int64_t n_quads = (int64_t)env->tb.T * rows * (ROWF / 4);
-    // (until round 6 each wave converted its chunk's 16 rows itself: 158 vector instructions per chunk, and the 2 or 3
-    // tiles of a (county, year) converted the same rows)
-    hipLaunchKernelGGL(k_pi8_xd, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, env->tb.X, xs, n_quads, xd);
+    hipLaunchKernelGGL(k_rm_xd, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, env->tb.X, xs, n_quads, xd);
     HIP_TRY(hipGetLastError());
     env->rm_ws = workspace;
   }
@@ -862,7 +849,7 @@ int w2a_rollout_posterior_mean(w2a_env *env, const w2a_policy *policy, int32_t n
   if (i8) {
     PmI8RolloutArgs ia;
     ia.r = a; ia.perm = env->perm; ia.tiles = env->tiles_i8; ia.n_tiles = env->n_tiles_i8; ia.wq = env->wq;
-    ia.wscale = env->wscale; ia.colflag = env->colflag; ia.xs = env->xs; ia.xd = env->xd;
+    ia.wscale = env->wscale; ia.colflag = env->colflag; ia.xs = env->xs;
     const unsigned grid8 = (unsigned)((max_tiles_i8(env->n, env->tb.S) + 7) / 8 * 8);
     hipLaunchKernelGGL(k_pm_rollout_i8, dim3(grid8), dim3(PI8_THREADS), 0, s, ia);
     HIP_TRY(hipGetLastError());

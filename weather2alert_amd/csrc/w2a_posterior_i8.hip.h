@@ -140,7 +140,6 @@ struct PmI8Args {
   const float *wscale;       // [S * n_samples * 2]
   const uint32_t *colflag;   // [S] 1 = some coefficient row of the column is outside the fixed-point range
   const float *xs;           // [64] slot scales (k_pi8_scales)
-  const uint32_t *xd;        // digit planes of the feature table (k_pi8_xd)
 };
 
 // 4 x 4 byte transpose: d[c] = packed digits of slot 4g + c  ->  plane words (plane p = byte 3 - p of every slot)
@@ -161,43 +160,27 @@ __device__ __forceinline__ float pi8_add_dpp(float v) {
 }
 
 // ---- pieces shared by k_posterior_mean_i8 (one day per launch) and k_pm_rollout_i8 (a whole episode per launch) ------
-// ---- once per table: the feature table as digit planes, [row of X][4 planes][8 words] (the layout of one row of the X
-// image). The 28 table-sourced slots of a row never change, so their conversion (7 of a row's 8 quads: ~150 of the ~180
-// vector instructions pi8_store_row spends per row) is done here once instead of per env-step / per 16-day chunk; the
-// run-time quad (slots 24..27) is converted where the env's state is. Same truncating conversion: bit-identical images.
-__global__ void k_pi8_xd(const float4 *X, const float *xs, int64_t n_quads, uint32_t *xd) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_quads) return;
-  const int g = (int)(i & 7);
-  const float4 v = X[i];
-  uint32_t d[4], o[4];
-  d[0] = pi8_digits((int32_t)(v.x * xs[4 * g]));
-  d[1] = pi8_digits((int32_t)(v.y * xs[4 * g + 1]));
-  d[2] = pi8_digits((int32_t)(v.z * xs[4 * g + 2]));
-  d[3] = pi8_digits((int32_t)(v.w * xs[4 * g + 3]));
-  pi8_planes(d, o);
-  uint32_t *row = xd + (i >> 3) * ROWF;
+// a row's 32 floats -> fixed-point digits -> its 128 B of the X image (4 planes x 32 slots; 8 x 16-B stores, consecutive
+// rows sit 4 banks apart)
+__device__ __forceinline__ void pi8_store_row(const float4 (&xf)[ROWF / 4], const float *xs, uint32_t *row) {
+  uint32_t pl[4][ROWF / 4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) row[8 * p + g] = o[p];
-}
-// a row of the X image from the table's digit planes + the env's run-time fields (slots 24..27 = quad 6 = word 6 of every
-// plane): 8 x 16-B loads, one quad converted, 8 x 16-B stores
-__device__ __forceinline__ void pi8_store_row_xd(const uint32_t *xd_row, const float4 rt, const float *xs, uint32_t *row) {
-  const uint4 *src = reinterpret_cast<const uint4 *>(xd_row);
-  uint4 dg[ROWF / 4];
+  for (int g = 0; g < ROWF / 4; ++g) {
+    uint32_t d[4], o[4];
+    d[0] = pi8_digits((int32_t)(xf[g].x * xs[4 * g]));      // truncating convert: |x| < 2^ex_k by construction
+    d[1] = pi8_digits((int32_t)(xf[g].y * xs[4 * g + 1]));
+    d[2] = pi8_digits((int32_t)(xf[g].z * xs[4 * g + 2]));
+    d[3] = pi8_digits((int32_t)(xf[g].w * xs[4 * g + 3]));
+    pi8_planes(d, o);
 #pragma unroll
-  for (int i = 0; i < ROWF / 4; ++i) dg[i] = src[i];
-  uint32_t d[4], o[4];
-  d[0] = pi8_digits((int32_t)(rt.x * xs[4 * RT_QUAD]));
-  d[1] = pi8_digits((int32_t)(rt.y * xs[4 * RT_QUAD + 1]));
-  d[2] = pi8_digits((int32_t)(rt.z * xs[4 * RT_QUAD + 2]));
-  d[3] = pi8_digits((int32_t)(rt.w * xs[4 * RT_QUAD + 3]));
-  pi8_planes(d, o);
-  static_assert(RT_QUAD == 6, "word 6 of a plane = component z of its second uint4");
-  dg[1].z = o[0]; dg[3].z = o[1]; dg[5].z = o[2]; dg[7].z = o[3];
+    for (int p = 0; p < 4; ++p) pl[p][g] = o[p];
+  }
   uint4 *dst = reinterpret_cast<uint4 *>(row);
 #pragma unroll
-  for (int i = 0; i < ROWF / 4; ++i) dst[i] = dg[i];
+  for (int p = 0; p < 4; ++p) {
+    dst[2 * p] = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    dst[2 * p + 1] = make_uint4(pl[p][4], pl[p][5], pl[p][6], pl[p][7]);
+  }
 }
 // the wave's A fragments: row tiles wave, wave + 4, ...; lane (c16, q) holds 16 slots of one plane of row c16
 __device__ __forceinline__ void pi8_load_a(const uint32_t (*sX)[PI8_XSTRIDE], int wave, int lane, pi8_v4i *P, pi8_v4i *Q) {
@@ -357,16 +340,17 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
   // ---- lane = row: record and feature row of the day
   uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
   if (tid < rows) rec = PM_REC(a.p, tl.x + tid);
-  const float4 rt = make_float4((float)(rec.y & 1u), (float)((rec.y >> 1) & 1023u), (float)(rec.y >> 16),
-                                (float)((rec.y >> 11) & 15u));
-  const uint32_t ga = (tid < rows) ? (rec.y >> 15) & 1u : 0u;
-  if (a.colflag[col]) {
-    // ---- exact path for a column outside the fixed-point range: fp64 dot products straight from W (uniform addresses)
-    float4 xf[ROWF / 4];
+  float4 xf[ROWF / 4];
+  {
     const float4 *xp = a.p.tb.X + (rec.x >> 2);
 #pragma unroll
     for (int q = 0; q < ROWF / 4; ++q) xf[q] = xp[q];
-    xf[RT_QUAD] = rt;
+    xf[RT_QUAD] = make_float4((float)(rec.y & 1u), (float)((rec.y >> 1) & 1023u), (float)(rec.y >> 16),
+                              (float)((rec.y >> 11) & 15u));
+  }
+  const uint32_t ga = (tid < rows) ? (rec.y >> 15) & 1u : 0u;
+  if (a.colflag[col]) {
+    // ---- exact path for a column outside the fixed-point range: fp64 dot products straight from W (uniform addresses)
     if (tid < rows)
       a.p.reward[rec.w] = (float)(-(1000.0 / 152.0) * pi8_exact_row(xf, a.p.tb.W, col, n_samples, ga) / (double)n_samples);
     return;
@@ -385,8 +369,8 @@ __global__ __launch_bounds__(PI8_THREADS, W2A_PI8_MIN_WAVES) void k_posterior_me
   const uint32_t pos = ga ? before : n_eff + ((uint32_t)tid - before);
   sEnv[pos] = rec.w;
   sGa[pos] = (float)ga;
-  // ---- fixed-point digits of the row -> LDS image: the table part from the table's digit planes, the run-time quad here
-  pi8_store_row_xd(a.xd + rec.x, rt, a.xs, sX[pos]);
+  // ---- fixed-point digits of the row -> LDS image
+  pi8_store_row(xf, a.xs, sX[pos]);
   const int eff_tiles = (int)((n_eff + 15u) >> 4);
   float rs[PI8_MT_PER_WAVE][4];  // per lane: sums over its draw columns of the 4 accumulator rows
 #pragma unroll

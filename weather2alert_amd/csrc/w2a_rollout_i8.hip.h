@@ -21,7 +21,6 @@ struct PmI8RolloutArgs {
   const float *wscale;
   const uint32_t *colflag;
   const float *xs;
-  const uint32_t *xd;        // digit planes of the feature table (k_pi8_xd)
 };
 
 __global__ __launch_bounds__(PI8_THREADS, 2) void k_pm_rollout_i8(const PmI8RolloutArgs pa) {
@@ -85,18 +84,19 @@ __global__ __launch_bounds__(PI8_THREADS, 2) void k_pm_rollout_i8(const PmI8Roll
     const uint32_t used2 = used + actual;
     const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
     const uint32_t day_row = t * rows_per_day + cold.x;
-    const float today = (kind == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
-    const float4 rt = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak, (float)(budget - (int32_t)used2),
-                                  (float)__popc(hist2));
-    // effectiveness enters through eff * gate * actual (env.py:218-221); inactive rows take no part
-    const uint32_t ga = (active && actual && Xf[(size_t)day_row * ROWF + 4 * GATE_QUAD + 2] > 0.5f) ? 1u : 0u;
-    double contrib;
-    if (exact) {  // workgroup-uniform
-      float4 xf[ROWF / 4];
+    float4 xf[ROWF / 4];
+    {
       const float4 *xp = a.tb.X + (size_t)day_row * (ROWF / 4);
 #pragma unroll
       for (int q = 0; q < ROWF / 4; ++q) xf[q] = xp[q];
-      xf[RT_QUAD] = rt;
+    }
+    const float today = (kind == W2A_POLICY_THRESHOLD) ? Xf[(size_t)day_row * ROWF + a.pol_slot] : 0.0f;
+    xf[RT_QUAD] = make_float4((t > 0) ? (float)actual : 0.0f, (float)streak, (float)(budget - (int32_t)used2),
+                              (float)__popc(hist2));
+    // effectiveness enters through eff * gate * actual (env.py:218-221); inactive rows take no part
+    const uint32_t ga = (active && actual && xf[GATE_QUAD].z > 0.5f) ? 1u : 0u;
+    double contrib;
+    if (exact) {
       contrib = active ? pi8_exact_row(xf, a.tb.W, col, n_samples, ga) : 0.0;
     } else {
       // rows with gate * actual = 1 first (stable partition inside the workgroup), as in k_posterior_mean_i8
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(PI8_THREADS, 2) void k_pm_rollout_i8(const PmI8Roll
       n_eff = __builtin_amdgcn_readfirstlane(n_eff);
       const uint32_t pos = ga ? before : n_eff + ((uint32_t)tid - before);
       sGa[pos] = (float)ga;
-      pi8_store_row_xd(pa.xd + (size_t)day_row * ROWF, rt, pa.xs, sX[pos]);
+      pi8_store_row(xf, pa.xs, sX[pos]);
       __syncthreads();  // the X image of the day is complete
       pi8_v4i P[PI8_MT_PER_WAVE], Q[PI8_MT_PER_WAVE];
       pi8_load_a(sX, wave, lane, P, Q);

@@ -37,7 +37,7 @@ struct RmArgs {
   const float *wscale;      // [S * n_samples * 2]  2^(ew - 20)
   const uint32_t *rowflag;  // [S * n_samples]  1 = a head of this coefficient row is outside the fixed-point range
   const float *xs;          // [64] slot scales
-  const uint32_t *xd;       // [T][S_w * Y][4 planes][8 words] int8 digit planes of the feature table (k_pi8_xd)
+  const uint32_t *xd;       // [T][S_w * Y][4 planes][8 words] int8 digit planes of the feature table (k_rm_xd)
 };
 
 // coefficient rows -> digit planes for this kernel: slots 24..27 (run-time fields) zeroed, scale in natural units,
@@ -79,6 +79,25 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
     dst[2 * p + 1] = make_uint4(planes[p][4], planes[p][5], planes[p][6], planes[p][7]);
   }
   wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
+}
+// feature rows -> digit planes, once per table: the B operands of every 16-day chunk of every tile come from here (until
+// round 6 each wave converted its chunk's 16 rows itself: 158 vector instructions per chunk, and the 2 or 3 tiles of a
+// (county, year) converted the same rows). One thread per (row of X, slot quad); the same truncating conversion as
+// pi8_store_row, plane-major words like the staged image it replaces.
+__global__ void k_rm_xd(const float4 *X, const float *xs, int64_t n_quads, uint32_t *xd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_quads) return;
+  const int g = (int)(i & 7);
+  const float4 v = X[i];
+  uint32_t d[4], o[4];
+  d[0] = pi8_digits((int32_t)(v.x * xs[4 * g]));
+  d[1] = pi8_digits((int32_t)(v.y * xs[4 * g + 1]));
+  d[2] = pi8_digits((int32_t)(v.z * xs[4 * g + 2]));
+  d[3] = pi8_digits((int32_t)(v.w * xs[4 * g + 3]));
+  pi8_planes(d, o);
+  uint32_t *row = xd + (i >> 3) * ROWF;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) row[8 * p + g] = o[p];
 }
 // the tile list: <= 64 consecutive positions of the visiting order that share one feature row; one thread per row, from
 // the row starts and tile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)

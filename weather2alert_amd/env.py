@@ -249,7 +249,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
         self._group_ws = None
         if reward_mode == "posterior_mean":
             with torch.cuda.device(dev):
-                self._group_ws = torch.empty(self._lib.w2a_group_workspace_bytes(n, ct.S, ct.n_samples, ct.S_w * ct.Y, ct.T), dtype=torch.uint8,
+                self._group_ws = torch.empty(self._lib.w2a_group_workspace_bytes(n, ct.S, ct.n_samples), dtype=torch.uint8,
                                              device=dev)
         nd = np.unique(ct.n_days)
         uniform = len(nd) == 1 and nd[0] > 0
