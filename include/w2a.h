@@ -335,11 +335,8 @@ int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, voi
  * feature row from that order and, once per table, builds a digit table of W in the workspace). Used by w2a_rollout
  * while the handle knows the batch to be in lock step and no corrected-semantics flag is set; results agree with the
  * other rollout kernels to the accuracy of the fixed point (returns within ~1e-6 relative), integers identical.
- * workspace: caller-owned, w2a_rollout_mfma_workspace_bytes(...) bytes, 256-B aligned, alive while w2a_rollout is used.
- * It holds, once per table, the int8 digit planes of W and (since ABI 18, hence the T argument) of the feature table X
- * itself -- as large as X: T * S_w * Y * 128 B, 160 MB on the reference's tables -- from which every 16-day chunk of every
- * tile takes its B operands. */
-size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples, int32_t T);
+ * workspace: caller-owned, w2a_rollout_mfma_workspace_bytes(...) bytes, 256-B aligned, alive while w2a_rollout is used. */
+size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples);
 int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 
 /* w2a_rollout with the posterior-mean reward (w2a_posterior_mean_reward's value every day), whole episode in one launch:

@@ -121,7 +121,7 @@ def load(build_if_missing: bool = True):
     lib.w2a_set_posterior_kernel.restype = C.c_int
     lib.w2a_set_posterior_kernel.argtypes = [vp, C.c_int]
     lib.w2a_rollout_mfma_workspace_bytes.restype = C.c_size_t
-    lib.w2a_rollout_mfma_workspace_bytes.argtypes = [i64, i64, i32, i32, i32]
+    lib.w2a_rollout_mfma_workspace_bytes.argtypes = [i64, i64, i32, i32]
     lib.w2a_rollout_mfma_prepare.restype = C.c_int
     lib.w2a_rollout_mfma_prepare.argtypes = [vp, vp, C.c_size_t, vp]
     lib.w2a_query.restype = C.c_int

@@ -207,7 +207,6 @@ struct w2a_env {
   const float *rm_wscale;
   const uint32_t *rm_rowflag;
   const float *rm_xs;
-  const uint32_t *rm_xd;         // digit planes of the feature table, in the same workspace
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   // which form of the per-env step state is current, what is known about days and budgets, which derived structures
   // are still valid: w2a_bookkeeping.h (plain C++, exercised on the CPU under sanitizers by tests/test_bookkeeping_cpu.py)

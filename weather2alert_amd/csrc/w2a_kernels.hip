@@ -697,20 +697,18 @@ int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, voi
 
 // ---- matrix-core rollout: workspace, preparation -------------------------------------------------------------------
 static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 63) / 64) + (size_t)rows; }
-size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples, int32_t T) {
-  if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0 || T <= 0)
-    return 0;
+size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples) {
+  if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0) return 0;
   const size_t w_rows = (size_t)S * n_samples * 2;
   return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 +
-         align256(w_rows * ROWF * 4) + align256(w_rows * 4) + align256(2 * w_rows) + 3 * 256 +
-         align256((size_t)T * (size_t)table_rows * ROWF * 4);  // the digit planes of the feature table: as large as X itself
+         align256(w_rows * ROWF * 4) + align256(w_rows * 4) + align256(2 * w_rows) + 3 * 256;
 }
 
 int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
   if (!env || !workspace) return fail(W2A_ERR_ARG, "w2a_rollout_mfma_prepare: NULL argument");
   REFUSE_WHILE_CAPTURING("w2a_rollout_mfma_prepare", stream);
   const int64_t rows = (int64_t)env->tb.S_w * env->tb.Y;
-  if (workspace_bytes < w2a_rollout_mfma_workspace_bytes(env->n, rows, env->tb.S, env->tb.n_samples, env->tb.T))
+  if (workspace_bytes < w2a_rollout_mfma_workspace_bytes(env->n, rows, env->tb.S, env->tb.n_samples))
     return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace too small");
   if ((uintptr_t)workspace & 255) return fail(W2A_ERR_STATE, "w2a_rollout_mfma_prepare: workspace must be 256-B aligned");
   if (!env->order || !env->order_start)
@@ -725,9 +723,8 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
   uint32_t *xmax_bits = (uint32_t *)p;  p += 256;
   uint32_t *bmax = (uint32_t *)p;       p += 256;
   float *xs = (float *)p;               p += 256;
-  uint32_t *xd = (uint32_t *)p;
   hipStream_t s = (hipStream_t)stream;
-  if (env->rm_ws != workspace) {  // once per table and workspace: slot scales, the digit tables of W and of X
+  if (env->rm_ws != workspace) {  // once per table and workspace: slot scales and the digit table of W
     HIP_TRY(hipMemsetAsync(xmax_bits, 0, 512, s));  // slot maxima and the (unused here) budget maximum
     HIP_TRY(hipMemsetAsync(rowflag, 0, 2 * w_rows, s));
     hipLaunchKernelGGL(k_pi8_slot_max, dim3(2048), dim3(256), 0, s, env->tb.X,
@@ -735,8 +732,6 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
     hipLaunchKernelGGL(k_pi8_scales, dim3(1), dim3(64), 0, s, xmax_bits, bmax, env->tb.T, xs);
     hipLaunchKernelGGL(k_rm_wq, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, wq, wscale, rowflag);
-    const int64_t n_quads = (int64_t)env->tb.T * rows * (ROWF / 4);
-    hipLaunchKernelGGL(k_rm_xd, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, env->tb.X, xs, n_quads, xd);
     HIP_TRY(hipGetLastError());
     env->rm_ws = workspace;
   }
@@ -746,7 +741,7 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
                      (int32_t)rows, tiles, n_tiles);
   HIP_TRY(hipGetLastError());
   env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq; env->rm_wscale = wscale; env->rm_rowflag = rowflag;
-  env->rm_xs = xs; env->rm_xd = xd;
+  env->rm_xs = xs;
   bk_rm_prepared(env->bk);
   return W2A_OK;
 }
@@ -790,7 +785,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     // feature-row tile list (w2a_rollout_mfma_prepare) and a batch in lock step
     RmArgs ra;
     ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.wscale = env->rm_wscale;
-    ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs; ra.xd = env->rm_xd;
+    ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs;
     const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());

@@ -37,7 +37,6 @@ struct RmArgs {
   const float *wscale;      // [S * n_samples * 2]  2^(ew - 20)
   const uint32_t *rowflag;  // [S * n_samples]  1 = a head of this coefficient row is outside the fixed-point range
   const float *xs;          // [64] slot scales
-  const uint32_t *xd;       // [T][S_w * Y][4 planes][8 words] int8 digit planes of the feature table (k_rm_xd)
 };
 
 // coefficient rows -> digit planes for this kernel: slots 24..27 (run-time fields) zeroed, scale in natural units,
@@ -80,25 +79,6 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
   }
   wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
 }
-// feature rows -> digit planes, once per table: the B operands of every 16-day chunk of every tile come from here (until
-// round 6 each wave converted its chunk's 16 rows itself: 158 vector instructions per chunk, and the 2 or 3 tiles of a
-// (county, year) converted the same rows). One thread per (row of X, slot quad); the same truncating conversion as
-// pi8_store_row, plane-major words like the staged image it replaces.
-__global__ void k_rm_xd(const float4 *X, const float *xs, int64_t n_quads, uint32_t *xd) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_quads) return;
-  const int g = (int)(i & 7);
-  const float4 v = X[i];
-  uint32_t d[4], o[4];
-  d[0] = pi8_digits((int32_t)(v.x * xs[4 * g]));
-  d[1] = pi8_digits((int32_t)(v.y * xs[4 * g + 1]));
-  d[2] = pi8_digits((int32_t)(v.z * xs[4 * g + 2]));
-  d[3] = pi8_digits((int32_t)(v.w * xs[4 * g + 3]));
-  pi8_planes(d, o);
-  uint32_t *row = xd + (i >> 3) * ROWF;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) row[8 * p + g] = o[p];
-}
 // the tile list: <= 64 consecutive positions of the visiting order that share one feature row; one thread per row, from
 // the row starts and tile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)
 __global__ void k_rm_tiles(const uint32_t *start, const uint32_t *tile_start, int32_t rows, uint4 *tiles, uint32_t *n_tiles) {
@@ -119,6 +99,7 @@ __global__ void k_rm_tiles(const uint32_t *start, const uint32_t *tile_start, in
 template <int KIND, bool MASKS>
 __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(const RmArgs ra) {
   const RolloutArgs &a = ra.r;
+  __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
   __shared__ __attribute__((aligned(16))) float sZ[RM_WAVES][64][RM_ZSTRIDE];                                      // logit parts [env][day * 2 + head]
   __shared__ float sDay[RM_WAVES][16][2];  // per day of the chunk: gate flag (slot 30), the threshold policy's feature
   const int lane = threadIdx.x & 63;
@@ -189,16 +170,41 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   const bool ends = !fin_u && total == (int)(nd_u - t_first);     // ... the terminal one among them
   uint32_t tu = t_first;                                          // today
   // threshold policy: the lagging observation (row of day t - 1, Q6) is carried from day to day; obs_lag = 0 reads today's
+  const int pol_quad = kind == W2A_POLICY_THRESHOLD ? (a.pol_slot >> 2) : -1, pol_comp = a.pol_slot & 3;
   float feat = 0.0f;
   if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t_first > 0)
     feat = Xf[((size_t)((t_first - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
   for (uint32_t c0 = t_first; total > 0; c0 += 16) {
-    // ---- B operands (day column c16): B_m = (X_m | X_{m-1}), straight from the table's digit planes: four 16-B loads per
-    // lane, together the whole 128-B digit rows of the chunk's 16 days of this (county, year)
+    // ---- feature digits of days c0 .. c0 + 15 of this (county, year): lane = (day, two slot groups)
+    {
+      const int j = lane >> 2, g0 = (lane & 3) * 2;
+      const uint32_t day = min(c0 + (uint32_t)j, (uint32_t)a.tb.T - 1u);
+      const float4 *xp = a.tb.X + ((size_t)day * rows_per_day + frow) * (ROWF / 4);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = g0 + gg;
+        const float4 v = xp[g];
+        uint32_t d[4], o[4];
+        d[0] = pi8_digits((int32_t)(v.x * ra.xs[4 * g]));
+        d[1] = pi8_digits((int32_t)(v.y * ra.xs[4 * g + 1]));
+        d[2] = pi8_digits((int32_t)(v.z * ra.xs[4 * g + 2]));
+        d[3] = pi8_digits((int32_t)(v.w * ra.xs[4 * g + 3]));
+        pi8_planes(d, o);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = o[p];
+        // what the day loop reads of the row itself: the tile's envs share it, so it is staged here once per chunk
+        // instead of being fetched by every lane on every day (a dependent global load per day: the loop's latency)
+        if (g == GATE_QUAD) sDay[wave][j][0] = v.z;
+        if (g == pol_quad) sDay[wave][j][1] = pol_comp == 0 ? v.x : pol_comp == 1 ? v.y : pol_comp == 2 ? v.z : v.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- B operands (day column c16): B_m = (X_m | X_{m-1})
     pi8_v4i B[4];
     {
-      const uint32_t dayb = min(c0 + (uint32_t)c16, (uint32_t)a.tb.T - 1u);
-      const uint32_t *x = ra.xd + ((size_t)dayb * rows_per_day + frow) * ROWF;
+      const uint32_t *x = sXd[wave][c16];
       const int half = 4 * (q & 1);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -206,14 +212,6 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
         const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(x + 8 * max(plane, 0) + half);
         B[m] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
       }
-    }
-    // what the day loop reads of the float rows themselves -- the gate flag (slot 30) and the threshold policy's feature --
-    // staged once per chunk for the tile's envs, which share the row (a dependent global load per lane and day otherwise)
-    if (lane < 16) {
-      const uint32_t day = min(c0 + (uint32_t)lane, (uint32_t)a.tb.T - 1u);
-      const float *xr = Xf + ((size_t)day * rows_per_day + frow) * ROWF;
-      sDay[wave][lane][0] = xr[4 * GATE_QUAD + 2];
-      if (kind == W2A_POLICY_THRESHOLD) sDay[wave][lane][1] = xr[a.pol_slot];
     }
     // ---- 4 row tiles x 2 heads: six MFMAs each, int32 sums -> f32 logit part -> sZ[env][day][head]
 #pragma unroll

@@ -831,7 +831,7 @@ class HeatAlertVecEnv(_VectorEnvBase):
                 if self.rollout_mfma and not (self.fixes - {"budget"}):
                     if self._mfma_ws is None:
                         self._mfma_ws = torch.empty(self._lib.w2a_rollout_mfma_workspace_bytes(
-                            n, ct.S_w * ct.Y, ct.S, ct.n_samples, ct.T), dtype=torch.uint8, device=dev)
+                            n, ct.S_w * ct.Y, ct.S, ct.n_samples), dtype=torch.uint8, device=dev)
                     _ffi.check(self._lib.w2a_rollout_mfma_prepare(self._h, self._mfma_ws.data_ptr(), self._mfma_ws.numel(),
                                                                   self._stream()), "w2a_rollout_mfma_prepare")
             if self._pm:
