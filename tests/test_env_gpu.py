@@ -1318,6 +1318,21 @@ def test_checkpoint_resume_is_bit_exact(dev, mode):
         o2, r2, d2, _, _ = other.step(a)
         assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
     assert torch.equal(env.state()["episode_no"], other.state()["episode_no"])
+    # a checkpoint written by ANOTHER build of the library (the lock-step mirror behind the canonical words changed size with
+    # ABI 17): its canonical prefix -- header, cold, hot3, stepc, the same layout in every version -- is what a restore needs;
+    # anything shorter is refused with a message instead of an opaque size mismatch
+    a256 = lambda x: (x + 255) & ~255  # noqa: E731
+    canon = 256 + a256(16 * n) + 2 * a256(12 * n)
+    old_ck = dict(ck, state=ck["state"][:canon + 512].clone(), host={k: v for k, v in ck["host"].items() if k not in ("abi_version", "state_bytes")})
+    third = HeatAlertVecEnv(n, tables=ct, device=dev, similar_climate_counties=True, reward_mode=mode)
+    third.reset(seed=5)
+    third.load_state_dict(old_ck)
+    for a, (o, r, d) in zip(acts[120:160], ref):
+        o2, r2, d2, _, _ = third.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    with pytest.raises(ValueError, match="canonical bytes"):
+        third.load_state_dict(dict(ck, state=ck["state"][:canon - 256].clone()))
+    third.close()
     env.close()
     other.close()
 

@@ -375,10 +375,18 @@ static size_t cub_sort_bytes(int64_t n) {
   return b;
 }
 
+// The fused sorted reset's radix sort goes to rocprim directly with the merge-sort limit at 0: the library's default sends
+// batches of up to 1 048 576 items -- exactly BASELINE's 1 M envs -- to a merge sort (block sort + 10 merge passes, 150 us,
+// whatever the bit range: profiles/r06/kernel_stats_configs2_sorted.csv before this change) instead of the onesweep radix
+// sort, which needs 4 passes for the 28 key bits. Both are stable.
+using Sort32Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+static hipError_t sort32_pairs(void *tmp, size_t &bytes, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in,
+                               uint32_t *v_out, size_t n, unsigned end_bit, hipStream_t s) {
+  return rocprim::radix_sort_pairs<Sort32Config>(tmp, bytes, k_in, k_out, v_in, v_out, n, 0u, end_bit, s);
+}
 static size_t cub_sort32_bytes(int64_t n) {
   size_t b = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+  (void)sort32_pairs(nullptr, b, nullptr, nullptr, nullptr, nullptr, (size_t)n, 32u, nullptr);
   return b;
 }
 // what w2a_reset_device_rng_sorted lays out in the same workspace: keys in / out, indices in / out, {sticky, episode} pairs
@@ -462,7 +470,7 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
   hipLaunchKernelGGL(k_reset_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env->tb, a.rc, env->st, env->n, env->gid0,
                      restart_episodes ? 1 : 0, k_in, i_in, zw);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, end_bit, s));  // stable
+  HIP_TRY(sort32_pairs(p, cub_bytes, k_in, k_out, i_in, i_out, n, (unsigned)end_bit, s));  // stable
   const W2aBook before = env->bk;
   {
     HipDev d{env, s};
@@ -482,12 +490,7 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
   return W2A_OK;
 }
 
-static size_t cub_group_bytes(int64_t n) {
-  size_t b = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-  return b;
-}
+static size_t cub_group_bytes(int64_t n) { return cub_sort32_bytes(n); }  // the same onesweep sort (10 key bits: 2 passes)
 
 static size_t wd_bytes(int32_t S, int32_t n_samples) { return align256((size_t)S * n_samples * 2 * ROWF * sizeof(double)); }
 // tiles of the posterior-mean kernel: at most one partial tile per column on top of n / PMV_THREADS full ones
@@ -539,7 +542,7 @@ int w2a_group_by_column(w2a_env *env, void *workspace, size_t workspace_bytes, v
   HIP_TRY(hipGetLastError());
   int bits = 1;
   while ((1 << bits) < env->tb.S) ++bits;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, perm, (int)n, 0, bits, s));
+  HIP_TRY(sort32_pairs(p, cub_bytes, k_in, k_out, i_in, perm, n, (unsigned)bits, s));
   // tiles of <= PMV_THREADS sorted positions of one column each
   HIP_TRY(hipMemsetAsync(col_start, 0, 2 * align256(4 * (size_t)env->tb.S), s));
   hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k_out, col_start, col_end, env->n);
