@@ -591,7 +591,7 @@ def sharded_workload(wl, args, rank, world, device, torch, HeatAlertVecEnv, synt
 
 
 # ------------------------------------------------------------------------------------------ fabric traffic, live
-def live_traffic(workload: str, n: int, no_obs: bool, step_kernel: str, episode_order: str, variant: str, timeout_s: int = 240):
+def live_traffic(workload: str, n: int, no_obs: bool, step_kernel: str, episode_order: str, variant: str, timeout_s: int = 90):
     """roofline.traffic measured in THIS run: two child processes `rocprofv3 --pmc <counter> --kernel-trace -- python3
     tools/pmc_probe.py ...` (FETCH_SIZE, then WRITE_SIZE: separate passes, MI355X_MICROARCH.md HBM section), started after
     every timing of this process is over and its env is closed -- a counter pass cannot run inside a process that is
@@ -619,10 +619,20 @@ def live_traffic(workload: str, n: int, no_obs: bool, step_kernel: str, episode_
                    os.path.join(ROOT, "tools", "pmc_probe.py"), "--workload", workload, "--num-envs", str(n), "--steps", "16",
                    "--step-kernel", step_kernel, "--episode-order", episode_order] + (["--no-obs"] if no_obs else [])
             t0 = time.perf_counter()
-            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+            # its own process group: a pass that hangs is ended WITH the probe it started, not only the profiler's launcher
+            pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                out_s, err_s = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                return None, f"rocprofv3 --pmc {ctr} pass did not finish within {timeout_s} s"
             per_pass_s[ctr] = round(time.perf_counter() - t0, 1)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {ctr} pass exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}"
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass exited {pr.returncode}: {(err_s or out_s)[-300:]}"
             per = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
