@@ -1187,6 +1187,8 @@ def main():
         _w0.record(); _w1.record(); _w1.synchronize(); _w0.elapsed_time(_w1)
     import gc
 
+    first_ev = []
+
     def timed_region(segments: bool):
         """EXACTLY args.steps steps between barrier + device synchronisation on both sides; (wall seconds on this rank,
         device milliseconds). segments: also record the per-episode HIP events of the headline's kernel timing."""
@@ -1200,8 +1202,11 @@ def main():
         e0.record()
         if graph is None:
             seg_on = segments
-            for _ in range(args.steps):
+            for i in range(args.steps):
                 one_step()
+                if i == 0 and segments:  # behind the region's FIRST step launch: see `first_to_last` below
+                    first_ev.append(torch.cuda.Event(enable_timing=True))
+                    first_ev[-1].record()
             seg_on = False
         else:
             for _ in range(args.steps // args.graph):
@@ -1217,7 +1222,14 @@ def main():
         wdist.barrier()
         w = time.perf_counter() - t_start
         gc.enable()
-        return w, e0.elapsed_time(e1)
+        # device time from the completion of the region's first step launch to the completion of its last one: steps - 1
+        # back-to-back launches WITHOUT what precedes the first one. A region that starts on an idle GPU (it must: barrier +
+        # device synchronisation on both sides) pays ~50 us between the e0 marker and the first kernel's start -- the host's
+        # return to Python, the ctypes call, the doorbell, the wake-up -- which is launch latency, not launch DURATION; in a
+        # 20-step window it reads as 3 us per step (profiles/r06/window_gaps_driver_args.txt: the kernel trace of the same
+        # run shows 34.6 us per launch and no gaps where e0 -> e1 says 37.4)
+        first_to_last = first_ev[-1].elapsed_time(e1) if (segments and first_ev) else None
+        return w, e0.elapsed_time(e1), first_to_last
 
     # ---- multi-GPU: the same workload on ONE GPU of this very job, before the headline (the other ranks wait idle at a
     # barrier, so rank 0 has its GPU, its PCIe link and the host to itself): the denominator of `weak_efficiency`
@@ -1244,7 +1256,7 @@ def main():
         gather.wait()
         torch.cuda.synchronize()
 
-    wall, dev_ms = timed_region(segments=True)
+    wall, dev_ms, first_to_last_ms = timed_region(segments=True)
     wall = wdist.max_over_ranks(wall, device)
     stepno_head = stepno  # where the headline region ended (the extra region below moves on)
     # the form of the per-env state the step kernel streamed in the measured launches (read NOW: later read-backs of
@@ -1254,7 +1266,7 @@ def main():
     no_coll = None
     if world > 1:
         use_gather = False
-        w2, _ = timed_region(segments=False)
+        w2, _, _ = timed_region(segments=False)
         no_coll = wdist.max_over_ranks(w2, device)
         use_gather = True
     status = env.check_status()
@@ -1275,9 +1287,16 @@ def main():
     elif graph is None and args.steps < T - 1 and (stepno_head - args.steps) // T == (stepno_head - 1) // T and (stepno_head % T) != 0:
         # a timed region shorter than an episode that did not cross an episode boundary (the driver's --steps 20): its
         # launches are nothing but step kernels, so the HIP events around the region itself are the measurement
-        kernel_us = dev_ms * 1e3 / args.steps
-        kernel_timing = (f"HIP events on the launch stream around the {args.steps} back-to-back step launches of the timed "
-                         "region itself (no reset kernel, no collective inside)")
+        if first_to_last_ms is not None and args.steps > 1:
+            kernel_us = first_to_last_ms * 1e3 / (args.steps - 1)
+            kernel_timing = (f"HIP events on the launch stream inside the timed region itself (no reset kernel, no collective "
+                             f"in it): from behind its first step launch to behind its last = {args.steps - 1} back-to-back "
+                             f"launches; the whole region e0 -> e1 incl. the idle-GPU start latency reads "
+                             f"{dev_ms * 1e3 / args.steps:.2f} us per step (`region_us_per_step`)")
+        else:
+            kernel_us = dev_ms * 1e3 / args.steps
+            kernel_timing = (f"HIP events on the launch stream around the {args.steps} back-to-back step launches of the timed "
+                             "region itself (no reset kernel, no collective inside)")
     elif graph is None:
         k_steps = min(T - 2, 140)
         if env._host_auto and T - env._steps_in_episode <= k_steps:
@@ -1385,6 +1404,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic["bytes_per_launch"],
                          "kernel": kname, "avg_launch_us": per_launch_s * 1e6,
+                         "region_us_per_step": dev_ms * 1e3 / args.steps,  # e0 -> e1 over the whole timed region / K
                          "bytes_model": "compulsory", "compulsory_bytes_per_env_step": cb,
                          "units_per_launch": n,
                          "traffic_unit": "fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts "
