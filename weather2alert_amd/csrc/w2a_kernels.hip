@@ -699,7 +699,8 @@ int w2a_rollout_order(w2a_env *env, void *workspace, size_t workspace_bytes, voi
 }
 
 // ---- matrix-core rollout: workspace, preparation -------------------------------------------------------------------
-static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 63) / 64) + (size_t)rows; }
+// subtiles of <= 16 envs of one feature row (at most one partial one per row); a wave of k_rollout_mfma takes four
+static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 15) / 16) + (size_t)rows; }
 size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0) return 0;
   const size_t w_rows = (size_t)S * n_samples * 2;
@@ -789,7 +790,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     RmArgs ra;
     ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.wscale = env->rm_wscale;
     ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs;
-    const size_t wgs = (rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + RM_WAVES - 1) / RM_WAVES;
+    const size_t wgs = ((rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + 3) / 4 + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());
     end_call(env, s);

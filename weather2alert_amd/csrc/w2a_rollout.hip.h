@@ -41,8 +41,8 @@ struct RolloutArgs {
 //                  it holds the env's row anyway and the atomic hides behind its observation stores); k_order_rank is
 //                  the same pass for every other case (first use, masked resets, in-kernel autoresets, restores)
 //   scan           start[row] = first position of the row (exclusive scan of cnt, start[rows] = n) and, in the same pass,
-//                  tile_start[row] = first 64-env tile of the row (exclusive scan of ceil(cnt / 64)): the matrix-core
-//                  rollout's tile list needs no pass of its own (k_rm_tiles)
+//                  tile_start[row] = first 16-env subtile of the row (exclusive scan of ceil(cnt / 16)): the matrix-core
+//                  rollout's subtile list needs no pass of its own (k_rm_tiles)
 //   place          order[start[row] + rank[env]] = env: no atomics
 // (Until round 4: histogram atomics, scan, a second pass of returning atomics for the scatter, and a one-workgroup tile
 // list: 47 + 8 + 49 + 5 + 24 us per 1 M-env episode, profiles/r04/kernel_trace_rollout_bench.txt.)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void k_order_scan(const uint32_t *cnt, int32_
   const int chunk = (rows + 1023) / 1024;
   const int r0 = min(rows, tid * chunk), r1 = min(rows, r0 + chunk);
   uint32_t mine = 0, mine_t = 0;
-  for (int r = r0; r < r1; ++r) { const uint32_t c = cnt[r]; mine += c; mine_t += (c + 63u) >> 6; }
+  for (int r = r0; r < r1; ++r) { const uint32_t c = cnt[r]; mine += c; mine_t += (c + 15u) >> 4; }
   s_sum[tid] = mine; s_til[tid] = mine_t;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_order_scan(const uint32_t *cnt, int32_
   for (int r = r0; r < r1; ++r) {
     const uint32_t c = cnt[r];
     start[r] = run; tile_start[r] = run_t;
-    run += c; run_t += (c + 63u) >> 6;
+    run += c; run_t += (c + 15u) >> 4;
   }
   if (tid == 1023) { start[rows] = s_sum[1023]; tile_start[rows] = s_til[1023]; }
 }

@@ -17,11 +17,16 @@
 // 16 x 16 tile, same a-priori bound |dz| <= 1.5 * 2^(ew - 23.4); coefficient rows outside the fixed-point range
 // (rowflag) make their env compute the plain fp64 dot product per day instead (per lane, rare).
 //
-// One wave = one tile of <= 64 envs of ONE feature row (tile list of w2a_rollout_mfma_prepare), lock step required (every
-// env on the same day: the handle's bookkeeping, else k_rollout64 serves the call). Per 16-day chunk: 128 (day, slot
-// group) conversions -> the chunk's feature digits in the wave's LDS; 4 row tiles x 2 heads x 6 MFMAs; the int32 sums ->
-// f32 logit parts -> LDS [env][day][head]; then 16 days of k_rollout64's day loop with 3 + 3 fp64 FMAs in place of
-// 30 + 30. Outputs, RNG streams and state are those of k_rollout64 (indexed by env id).
+// One wave = FOUR SUBTILES of <= 16 envs, each of ONE feature row (subtile list of w2a_rollout_mfma_prepare: the envs of a
+// (county, year) in runs of 16, the last one partial) = the four 16-row tiles of the GEMM's M dimension; lock step required
+// (every env on the same day: the handle's bookkeeping, else k_rollout64 serves the call). Until round 6 a wave was one
+// tile of <= 64 envs of one feature row: at 1 M envs over 8 206 (county, year) rows -- 128 envs per row on average -- that
+// left a third of the lanes idle (24 592 waves for 16 384 x 64 envs) in a kernel whose cost is per wave-day; padding to
+// 16 instead of 64 wastes 6 %. Per 16-day chunk and subtile: the feature digits of its row's 16 days -> the wave's LDS
+// (128 (day, slot group) conversions; skipped when the subtile continues the previous one's row, which is the common
+// case: a row's ~8 subtiles sit in consecutive waves), B operands from there, 2 heads x 6 MFMAs, the int32 sums -> f32
+// logit parts -> LDS [env][day][head]; then 16 days of k_rollout64's day loop with 3 + 3 fp64 FMAs in place of 30 + 30.
+// Outputs, RNG streams and state are those of k_rollout64 (indexed by env id).
 #ifndef RM_WAVES
 #define RM_WAVES 1  // waves (= tiles) per workgroup: no workgroup-level synchronisation is used, and single-wave workgroups
                     // leave the dispatcher the finest grain (measured 0.87 / 0.88 / 0.90 ms per episode for 1 / 2 / 4)
@@ -79,15 +84,16 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
   }
   wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
 }
-// the tile list: <= 64 consecutive positions of the visiting order that share one feature row; one thread per row, from
-// the row starts and tile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)
+// the subtile list: <= 16 consecutive positions of the visiting order that share one feature row; one thread per row, from
+// the row starts and subtile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)
+#define RM_SUB 16u
 __global__ void k_rm_tiles(const uint32_t *start, const uint32_t *tile_start, int32_t rows, uint4 *tiles, uint32_t *n_tiles) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r == 0) *n_tiles = tile_start[rows];
   if (r >= rows) return;
   const uint32_t s0 = start[r], s1 = start[r + 1];
   uint32_t j = tile_start[r];
-  for (uint32_t st = s0; st < s1; st += 64u) tiles[j++] = make_uint4(st, min(64u, s1 - st), (uint32_t)r, 0u);
+  for (uint32_t st = s0; st < s1; st += RM_SUB) tiles[j++] = make_uint4(st, min(RM_SUB, s1 - st), (uint32_t)r, 0u);
 }
 
 // Compiled per policy kind and with / without the day bitmaps + return snapshot (like k_rollout64): with two waves per
@@ -101,23 +107,25 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   const RolloutArgs &a = ra.r;
   __shared__ __attribute__((aligned(16))) uint32_t sXd[RM_WAVES][16][PI8_XSTRIDE];  // feature digits of the chunk's days
   __shared__ __attribute__((aligned(16))) float sZ[RM_WAVES][64][RM_ZSTRIDE];                                      // logit parts [env][day * 2 + head]
-  __shared__ float sDay[RM_WAVES][16][2];  // per day of the chunk: gate flag (slot 30), the threshold policy's feature
+  __shared__ float sDay[RM_WAVES][4][16][2];  // per subtile and day of the chunk: gate flag (slot 30), the threshold policy's feature
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   // The grid is sized for the worst case (n / 64 + feature rows tiles); the tiles there are get an eighth per XCD, dealt
   // from the actual count -- with the grid's eighths the surplus workgroups would all fall on the last XCDs and leave
   // them idle (at 1 M envs / 8 206 rows: 20.5 K tiles of 24.6 K, XCD 7 empty and XCD 6 a third full: 1.03 -> 0.90 ms)
-  const uint32_t n_tiles = *ra.n_tiles;
+  const uint32_t n_sub = *ra.n_tiles;           // subtiles of <= 16 envs
+  const uint32_t n_tiles = (n_sub + 3u) >> 2;   // waves
   const uint32_t n_wgs = (n_tiles + RM_WAVES - 1) / RM_WAVES, per_xcd = (n_wgs + 7u) >> 3;
   if ((blockIdx.x >> 3) >= per_xcd) return;
   const uint32_t tile = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * RM_WAVES + wave;
   if (tile >= n_tiles) return;  // whole wave; only wave-level synchronisation below
-  const uint4 tl = ra.tiles[tile];
-  const int count = (int)__builtin_amdgcn_readfirstlane(tl.y);
-  const uint32_t frow = __builtin_amdgcn_readfirstlane(tl.z);
-  const bool valid = lane < count;
-  const uint32_t e = a.order[tl.x + (valid ? lane : 0)];
+  const int subs = (int)min(4u, n_sub - 4u * tile);  // subtiles of this wave (4 but for the last wave); wave-uniform
+  // lane (q, c16) = env c16 of subtile q; lanes past a subtile's end (and past the last subtile) shadow a valid env
+  const uint4 tl = ra.tiles[min(4u * tile + (uint32_t)q, n_sub - 1u)];
+  const uint32_t frow = tl.z;  // this lane's (county, year): up to four different ones per wave
+  const bool valid = q < subs && (uint32_t)c16 < tl.y;
+  const uint32_t e = a.order[tl.x + (valid ? (uint32_t)c16 : 0u)];
   uint4 c2, hot;
   load_step_state(a.st, e, c2, hot);
   const uint4 cold = load_cold(a.st, e);
@@ -170,53 +178,61 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   const bool ends = !fin_u && total == (int)(nd_u - t_first);     // ... the terminal one among them
   uint32_t tu = t_first;                                          // today
   // threshold policy: the lagging observation (row of day t - 1, Q6) is carried from day to day; obs_lag = 0 reads today's
-  const int pol_quad = kind == W2A_POLICY_THRESHOLD ? (a.pol_slot >> 2) : -1, pol_comp = a.pol_slot & 3;
   float feat = 0.0f;
   if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t_first > 0)
     feat = Xf[((size_t)((t_first - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
   for (uint32_t c0 = t_first; total > 0; c0 += 16) {
-    // ---- feature digits of days c0 .. c0 + 15 of this (county, year): lane = (day, two slot groups)
+    // ---- what the day loop reads of the float rows themselves -- the gate flag (slot 30) and the threshold policy's
+    // feature --, staged once per chunk: lane (q, c16) fetches day c0 + c16 of ITS subtile's row (the subtile's envs share
+    // the row; a dependent global load per lane and day otherwise: the loop's latency)
     {
-      const int j = lane >> 2, g0 = (lane & 3) * 2;
-      const uint32_t day = min(c0 + (uint32_t)j, (uint32_t)a.tb.T - 1u);
-      const float4 *xp = a.tb.X + ((size_t)day * rows_per_day + frow) * (ROWF / 4);
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int g = g0 + gg;
-        const float4 v = xp[g];
-        uint32_t d[4], o[4];
-        d[0] = pi8_digits((int32_t)(v.x * ra.xs[4 * g]));
-        d[1] = pi8_digits((int32_t)(v.y * ra.xs[4 * g + 1]));
-        d[2] = pi8_digits((int32_t)(v.z * ra.xs[4 * g + 2]));
-        d[3] = pi8_digits((int32_t)(v.w * ra.xs[4 * g + 3]));
-        pi8_planes(d, o);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = o[p];
-        // what the day loop reads of the row itself: the tile's envs share it, so it is staged here once per chunk
-        // instead of being fetched by every lane on every day (a dependent global load per day: the loop's latency)
-        if (g == GATE_QUAD) sDay[wave][j][0] = v.z;
-        if (g == pol_quad) sDay[wave][j][1] = pol_comp == 0 ? v.x : pol_comp == 1 ? v.y : pol_comp == 2 ? v.z : v.w;
-      }
+      const uint32_t day = min(c0 + (uint32_t)c16, (uint32_t)a.tb.T - 1u);
+      const float *xr = Xf + ((size_t)day * rows_per_day + frow) * ROWF;
+      sDay[wave][q][c16][0] = xr[4 * GATE_QUAD + 2];
+      if (kind == W2A_POLICY_THRESHOLD) sDay[wave][q][c16][1] = xr[a.pol_slot];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- B operands (day column c16): B_m = (X_m | X_{m-1})
+    // ---- per subtile m (= 16-row tile of the GEMM): the B operands of its row's 16 days, then 2 heads x 6 MFMAs
     pi8_v4i B[4];
-    {
-      const uint32_t *x = sXd[wave][c16];
-      const int half = 4 * (q & 1);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int plane = q < 2 ? m : m - 1;
-        const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(x + 8 * max(plane, 0) + half);
-        B[m] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
-      }
-    }
-    // ---- 4 row tiles x 2 heads: six MFMAs each, int32 sums -> f32 logit part -> sZ[env][day][head]
+    uint32_t row_in_lds = 0xFFFFFFFFu;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (16 * m >= count) continue;  // wave-uniform
+      if (m >= subs) continue;  // wave-uniform
+      const uint32_t fr = (uint32_t)__builtin_amdgcn_readlane((int)frow, 16 * m);
+      if (fr != row_in_lds) {  // wave-uniform: another (county, year) than the previous subtile's
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the previous subtile's B operands have been read)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // feature digits of days c0 .. c0 + 15 of that row: lane = (day, two slot groups)
+        const int j = lane >> 2, g0 = (lane & 3) * 2;
+        const uint32_t day = min(c0 + (uint32_t)j, (uint32_t)a.tb.T - 1u);
+        const float4 *xp = a.tb.X + ((size_t)day * rows_per_day + fr) * (ROWF / 4);
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = g0 + gg;
+          const float4 v = xp[g];
+          uint32_t d[4], o[4];
+          d[0] = pi8_digits((int32_t)(v.x * ra.xs[4 * g]));
+          d[1] = pi8_digits((int32_t)(v.y * ra.xs[4 * g + 1]));
+          d[2] = pi8_digits((int32_t)(v.z * ra.xs[4 * g + 2]));
+          d[3] = pi8_digits((int32_t)(v.w * ra.xs[4 * g + 3]));
+          pi8_planes(d, o);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = o[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // B operands (day column c16): B_i = (X_i | X_{i-1})
+        const uint32_t *x = sXd[wave][c16];
+        const int half = 4 * (q & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int plane = q < 2 ? i : i - 1;
+          const pi8_v4i v = *reinterpret_cast<const pi8_v4i *>(x + 8 * max(plane, 0) + half);
+          B[i] = plane >= 0 ? v : pi8_v4i{0, 0, 0, 0};
+        }
+        row_in_lds = fr;
+      }
       float z0[4];  // head 0's logit parts of the four accumulator rows, kept until head 1's are there: one 8-B store per row
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     const double wl_b = rtb.x, ws_b = rtb.y, wr_b = rtb.z, wl_e = rte.x, ws_e = rte.y, wr_e = rte.z;
     const int chunk = min(16, total);
     for (int dd = 0; dd < chunk; ++dd, ++tu) {
-      const float today = sDay[wave][dd][1], gate = sDay[wave][dd][0];
+      const float today = sDay[wave][q][dd][1], gate = sDay[wave][q][dd][0];
       const int32_t act = policy_action(kind, a.pol, pstream, tu, budget - (int32_t)used,
                                         (a.pol.obs_lag && tu > 0) ? feat : today);
       const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
