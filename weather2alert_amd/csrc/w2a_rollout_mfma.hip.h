@@ -187,6 +187,12 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   // Infinity-Cache hits at best). Without that a wave's chunk was a chain load -> convert -> LDS -> MFMA -> day loop with
   // the load exposed every time, and the kernel's time did not follow its instruction count
   // (profiles/r06/ab_digit_table.log, ab_rollout_subtiles.log).
+  // the three run-time coefficients of both heads (slots 24, 25, 26), as doubles for the whole launch. (Fetched again per
+  // chunk -- round 6's first version, to spare 12 registers in the matrix-core section -- they were 2 lines per env and
+  // chunk from rows that no L2 keeps across a 16-day loop: 2.7 GB of fabric traffic per launch, FETCH_SIZE 620 -> 1 078 MB,
+  // and the kernel sat at 520-540 us whatever else was done to it: profiles/r06/rollout_counters_mfma.log)
+  const float4 rtb = *reinterpret_cast<const float4 *>(Wf + 24), rte = *reinterpret_cast<const float4 *>(Wf + ROWF + 24);
+  const double wl_b = rtb.x, ws_b = rtb.y, wr_b = rtb.z, wl_e = rte.x, ws_e = rte.y, wr_e = rte.z;
   const uint32_t fr0 = (uint32_t)__builtin_amdgcn_readlane((int)frow, 0);
   float4 pv[2];
   auto request_chunk = [&](uint32_t c) {
@@ -277,17 +283,10 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ)
-    // the three run-time coefficients of both heads (slots 24, 25, 26) as doubles: fetched per chunk (two 16-B loads from
-    // the env's coefficient rows, cache hits) so that their 12 registers are not held through the matrix-core section
-    const float *wrt = Wf + 24;
-    asm volatile("" : "+v"(wrt));
-    const float4 rtb = *reinterpret_cast<const float4 *>(wrt), rte = *reinterpret_cast<const float4 *>(wrt + ROWF);
-    const double wl_b = rtb.x, ws_b = rtb.y, wr_b = rtb.z, wl_e = rte.x, ws_e = rte.y, wr_e = rte.z;
     const int chunk = min(16, total);
     // the next chunk's rows, in flight through this chunk's day loop. Scheduling barriers on both sides: the memory counter
     // is in-order, so a wait for ANY later load -- the coefficients above, were they issued behind these -- would also
     // wait for these; and hoisted above the fence they would be waited for right there
-    asm volatile("" ::"v"(wl_b), "v"(ws_b), "v"(wr_b), "v"(wl_e), "v"(ws_e), "v"(wr_e));  // converted = loaded: before the requests
     __builtin_amdgcn_sched_barrier(0);
     if (total > chunk) request_chunk(c0 + 16);
     __builtin_amdgcn_sched_barrier(0);
