@@ -204,8 +204,6 @@ struct w2a_env {
   const uint4 *rm_tiles;
   const uint32_t *rm_n_tiles;
   const uint32_t *rm_wq;
-  const float *rm_wscale;
-  const uint32_t *rm_rowflag;
   const float *rm_xs;
   const uint32_t *order; // visiting order of k_rollout (w2a_rollout_order), any permutation is correct; NULL = identity
   // which form of the per-env step state is current, what is known about days and budgets, which derived structures

@@ -704,8 +704,7 @@ static size_t rm_max_tiles(int64_t n, int64_t rows) { return (size_t)((n + 15) /
 size_t w2a_rollout_mfma_workspace_bytes(int64_t num_envs, int64_t table_rows, int32_t S, int32_t n_samples) {
   if (num_envs <= 0 || num_envs > (1ll << 27) || table_rows <= 0 || table_rows > 0x7FFFFFFFll || S <= 0 || n_samples <= 0) return 0;
   const size_t w_rows = (size_t)S * n_samples * 2;
-  return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 +
-         align256(w_rows * ROWF * 4) + align256(w_rows * 4) + align256(2 * w_rows) + 3 * 256;
+  return align256(16 * rm_max_tiles(num_envs, table_rows)) + 256 + align256(w_rows * ROWF * 4) + 3 * 256;
 }
 
 int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream) {
@@ -722,20 +721,17 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
   uint4 *tiles = (uint4 *)p;            p += align256(16 * rm_max_tiles(env->n, rows));
   uint32_t *n_tiles = (uint32_t *)p;    p += 256;
   uint32_t *wq = (uint32_t *)p;         p += align256(w_rows * ROWF * 4);
-  float *wscale = (float *)p;           p += align256(w_rows * 4);
-  uint32_t *rowflag = (uint32_t *)p;    p += align256(2 * w_rows);
   uint32_t *xmax_bits = (uint32_t *)p;  p += 256;
   uint32_t *bmax = (uint32_t *)p;       p += 256;
   float *xs = (float *)p;               p += 256;
   hipStream_t s = (hipStream_t)stream;
   if (env->rm_ws != workspace) {  // once per table and workspace: slot scales and the digit table of W
     HIP_TRY(hipMemsetAsync(xmax_bits, 0, 512, s));  // slot maxima and the (unused here) budget maximum
-    HIP_TRY(hipMemsetAsync(rowflag, 0, 2 * w_rows, s));
     hipLaunchKernelGGL(k_pi8_slot_max, dim3(2048), dim3(256), 0, s, env->tb.X,
                        (int64_t)env->tb.T * env->tb.S_w * env->tb.Y * (ROWF / 4), xmax_bits);
     hipLaunchKernelGGL(k_pi8_scales, dim3(1), dim3(64), 0, s, xmax_bits, bmax, env->tb.T, xs);
     hipLaunchKernelGGL(k_rm_wq, dim3((unsigned)((w_rows + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, wq, wscale, rowflag);
+                       reinterpret_cast<const float *>(env->tb.W), xs, (int64_t)w_rows, wq);
     HIP_TRY(hipGetLastError());
     env->rm_ws = workspace;
   }
@@ -744,7 +740,7 @@ int w2a_rollout_mfma_prepare(w2a_env *env, void *workspace, size_t workspace_byt
   hipLaunchKernelGGL(k_rm_tiles, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, env->order_start, env->order_tile_start,
                      (int32_t)rows, tiles, n_tiles);
   HIP_TRY(hipGetLastError());
-  env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq; env->rm_wscale = wscale; env->rm_rowflag = rowflag;
+  env->rm_tiles = tiles; env->rm_n_tiles = n_tiles; env->rm_wq = wq;
   env->rm_xs = xs;
   bk_rm_prepared(env->bk);
   return W2A_OK;
@@ -788,8 +784,7 @@ int w2a_rollout(w2a_env *env, const w2a_policy *policy, int32_t n_steps, float *
     // the table-sourced part of the logits on the int8 matrix cores (w2a_rollout_mfma.hip.h): needs the episode's
     // feature-row tile list (w2a_rollout_mfma_prepare) and a batch in lock step
     RmArgs ra;
-    ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.wscale = env->rm_wscale;
-    ra.rowflag = env->rm_rowflag; ra.xs = env->rm_xs;
+    ra.r = a; ra.tiles = env->rm_tiles; ra.n_tiles = env->rm_n_tiles; ra.wq = env->rm_wq; ra.xs = env->rm_xs;
     const size_t wgs = ((rm_max_tiles(env->n, (int64_t)env->tb.S_w * env->tb.Y) + 3) / 4 + RM_WAVES - 1) / RM_WAVES;
     launch_rollout_mfma(policy->kind, alert_mask || attempt_mask || ret_snapshot, (unsigned)((wgs + 7) / 8 * 8), s, ra);
     HIP_TRY(hipGetLastError());

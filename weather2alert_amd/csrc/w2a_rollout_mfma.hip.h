@@ -38,15 +38,20 @@ struct RmArgs {
   RolloutArgs r;
   const uint4 *tiles;       // (first position in the visiting order, envs, feature row, 0)
   const uint32_t *n_tiles;
-  const uint32_t *wq;       // [S * n_samples * 2][32] int8 digit planes of W, run-time slots zeroed
-  const float *wscale;      // [S * n_samples * 2]  2^(ew - 20)
-  const uint32_t *rowflag;  // [S * n_samples]  1 = a head of this coefficient row is outside the fixed-point range
+  const uint32_t *wq;       // [S * n_samples * 2][32] int8 digit planes of W; the words of the run-time slots carry the row's
+                            // scale, exact-path flag and run-time coefficients (k_rm_wq)
   const float *xs;          // [64] slot scales
 };
 
-// coefficient rows -> digit planes for this kernel: slots 24..27 (run-time fields) zeroed, scale in natural units,
-// one flag per (column, draw)
-__global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t *wq, float *wscale, uint32_t *rowflag) {
+// coefficient rows -> digit planes for this kernel, scale in natural units. The run-time slots 24..27 take no part in the
+// GEMM (their features follow the agent's actions; the kernel zeroes the feature digits of that quad), so word 6 of each
+// of a row's four planes is free -- and carries what the env's lane needs of the row besides the digits:
+//   plane 0: the row's scale 2^(ew - 20) as f32 bits, NEGATIVE if the row takes the exact path (a head outside the
+//            fixed-point range, or a coefficient on slot 27)          planes 1..3: the f32 coefficients of slots 24, 25, 26
+// They arrive with the A-operand loads the wave does anyway and are handed to the env's lane by lane shuffles. Until round
+// 6 the lane fetched them itself -- scale, flag and the two 16-B pieces of the float rows: four more cache lines per env,
+// by env id, in a launch whose fixed cost is exactly such lines (profiles/r06/exp_rollout_nsteps.log: 200 of 470 us).
+__global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t *wq) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float w[ROWF];
@@ -58,11 +63,10 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
   }
   int ew = 0;
   if (m > 0.0f) (void)frexpf(m, &ew);
-  if (ew > W2A_PI8_EW_MAX) atomicOr(&rowflag[r >> 1], 1u);
   // a coefficient on slot 27 (the agent's 14-day count: none in the faithful semantics, Q1 -- alert_2wks is an appended
   // observation key, not a reward feature) is honoured by the exact path, so that the common path carries three run-time
   // terms per head instead of four
-  if (W[r * ROWF + 27] != 0.0f) atomicOr(&rowflag[r >> 1], 1u);
+  const bool exact = ew > W2A_PI8_EW_MAX || W[r * ROWF + 27] != 0.0f;
   const float s = ldexpf(1.0f, 30 - ew);
   uint32_t planes[4][8];
 #pragma unroll
@@ -76,13 +80,17 @@ __global__ void k_rm_wq(const float *W, const float *xs, int64_t rows, uint32_t 
       planes[p][g] = ((d[0] >> sh) & 255u) | (((d[1] >> sh) & 255u) << 8) | (((d[2] >> sh) & 255u) << 16) | (((d[3] >> sh) & 255u) << 24);
     }
   }
+  const float scale = ldexpf(1.0f, ew - 20);  // z = scale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
+  planes[0][RT_QUAD] = __float_as_uint(exact ? -scale : scale);
+  planes[1][RT_QUAD] = __float_as_uint(W[r * ROWF + 24]);
+  planes[2][RT_QUAD] = __float_as_uint(W[r * ROWF + 25]);
+  planes[3][RT_QUAD] = __float_as_uint(W[r * ROWF + 26]);
   uint4 *dst = reinterpret_cast<uint4 *>(wq + r * ROWF);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     dst[2 * p] = make_uint4(planes[p][0], planes[p][1], planes[p][2], planes[p][3]);
     dst[2 * p + 1] = make_uint4(planes[p][4], planes[p][5], planes[p][6], planes[p][7]);
   }
-  wscale[r] = ldexpf(1.0f, ew - 20);  // z = wscale * (A0 2^8 + A1 + (A2 2^8 + A3) 2^-16)
 }
 // the subtile list: <= 16 consecutive positions of the visiting order that share one feature row; one thread per row, from
 // the row starts and subtile starts the order's scan left (k_order_scan). tiles[j] = (first position, envs, feature row, 0)
@@ -127,8 +135,9 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   const bool valid = q < subs && (uint32_t)c16 < tl.y;
   const uint32_t e = a.order[tl.x + (valid ? (uint32_t)c16 : 0u)];
   uint4 c2, hot;
-  load_step_state(a.st, e, c2, hot);
-  const uint4 cold = load_cold(a.st, e);
+  load_step_state(a.st, e, c2, hot);  // c2 = {ep_row, ep_w}: the copies in stepc
+  // the episode number keys the Bernoulli policy's stream; no other policy needs the env's cold record (one line per env)
+  const uint32_t episode_no = KIND == W2A_POLICY_BERNOULLI ? load_cold(a.st, e).w : 0u;
   uint32_t t = D0_T(hot.x), used = D0_USED(hot.x), streak = D0_STREAK(hot.x), last = D0_LAST(hot.x);
   uint32_t atb = D0_ATB(hot.x), hist = D1_HIST(hot.y);
   const uint32_t ndays = D1_NDAYS(hot.y);
@@ -136,14 +145,8 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   bool fin = D1_FIN(hot.y) != 0;
   float ret_total = __uint_as_float(hot.z);
   const uint32_t rows_per_day = (uint32_t)(a.tb.S_w * a.tb.Y);
-  const uint32_t wrow = W_COL(cold.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(cold.y);
-  const float *Wf = reinterpret_cast<const float *>(a.tb.W) + (size_t)wrow * (2 * ROWF);
-  const bool exact = ra.rowflag[wrow] != 0u;  // this env's coefficient row is outside the fixed-point range (or uses slot 27)
-  const bool any_exact = __any(exact) != 0;   // wave-uniform: the common case never enters the exact path's control flow
-  // the env's two row scales 2^(ew - 20): powers of two, applied by the env's own lane in the day loop (exact), so that the
-  // matrix-core section needs no per-row scale (until round 6 it read 32 of them from LDS per chunk, and the compiler kept
-  // them -- loop invariants -- in 32 + 32 registers through the whole launch: the kernel's spills)
-  const float sc_b = ra.wscale[(size_t)wrow * 2], sc_e = ra.wscale[(size_t)wrow * 2 + 1];
+  const uint32_t wrow = W_COL(c2.y) * (uint32_t)a.tb.n_samples + W_SAMPLE(c2.y);
+  const float *Wf = reinterpret_cast<const float *>(a.tb.W) + (size_t)wrow * (2 * ROWF);  // (read by the exact path only)
   // A operands: row tile m, lane (c16, q) holds 16 slots of one plane of env 16 m + c16 (its coefficient digits): 64
   // registers for the whole launch
   pi8_v4i P[4][2], Q[4][2];
@@ -157,8 +160,27 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
       Q[m][h] = *reinterpret_cast<const pi8_v4i *>(row + 16 + 4 * q);
     }
   }
+  // What rides in the run-time slot words of the digit rows (k_rm_wq): word 6 of plane 0 / 1 sits in component 2 of the P
+  // fragment of lane group q = 1 / 3, word 6 of plane 2 / 3 in component 2 of the Q fragment of lane group 1 / 3 -- of the
+  // lane with the env's c16. Each env's own lane (row tile m = its q) takes them by lane shuffles:
+  //   the two row scales 2^(ew - 20), powers of two, applied by the env's lane in the day loop (exact), so that the
+  //   matrix-core section needs no per-row scale; negative = the row takes the exact path; the three run-time
+  //   coefficients of both heads (slots 24, 25, 26) as doubles for the whole launch
+  float sc_b = 0.0f, sc_e = 0.0f;
+  double wl_b = 0.0, ws_b = 0.0, wr_b = 0.0, wl_e = 0.0, ws_e = 0.0, wr_e = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float s0 = __int_as_float(__shfl(P[m][0][2], 16 + c16)), s1 = __int_as_float(__shfl(P[m][1][2], 16 + c16));
+    const float l0 = __int_as_float(__shfl(P[m][0][2], 48 + c16)), l1 = __int_as_float(__shfl(P[m][1][2], 48 + c16));
+    const float k0 = __int_as_float(__shfl(Q[m][0][2], 16 + c16)), k1 = __int_as_float(__shfl(Q[m][1][2], 16 + c16));
+    const float r0 = __int_as_float(__shfl(Q[m][0][2], 48 + c16)), r1 = __int_as_float(__shfl(Q[m][1][2], 48 + c16));
+    if (q == m) { sc_b = s0; sc_e = s1; wl_b = l0; wl_e = l1; ws_b = k0; ws_e = k1; wr_b = r0; wr_e = r1; }
+  }
+  const bool exact = sc_b < 0.0f || sc_e < 0.0f;  // this env's coefficient row is outside the fixed-point range (or uses slot 27)
+  const bool any_exact = __any(exact) != 0;       // wave-uniform: the common case never enters the exact path's control flow
+  sc_b = fabsf(sc_b); sc_e = fabsf(sc_e);
   const float *Xf = reinterpret_cast<const float *>(a.tb.X);
-  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), cold.w);
+  const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), episode_no);
   constexpr int32_t kind = KIND;
   float ret = 0.0f;
   int32_t alerts = 0, over = 0;
@@ -187,12 +209,6 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   // Infinity-Cache hits at best). Without that a wave's chunk was a chain load -> convert -> LDS -> MFMA -> day loop with
   // the load exposed every time, and the kernel's time did not follow its instruction count
   // (profiles/r06/ab_digit_table.log, ab_rollout_subtiles.log).
-  // the three run-time coefficients of both heads (slots 24, 25, 26), as doubles for the whole launch. (Fetched again per
-  // chunk -- round 6's first version, to spare 12 registers in the matrix-core section -- they were 2 lines per env and
-  // chunk from rows that no L2 keeps across a 16-day loop: 2.7 GB of fabric traffic per launch, FETCH_SIZE 620 -> 1 078 MB,
-  // and the kernel sat at 520-540 us whatever else was done to it: profiles/r06/rollout_counters_mfma.log)
-  const float4 rtb = *reinterpret_cast<const float4 *>(Wf + 24), rte = *reinterpret_cast<const float4 *>(Wf + ROWF + 24);
-  const double wl_b = rtb.x, ws_b = rtb.y, wr_b = rtb.z, wl_e = rte.x, ws_e = rte.y, wr_e = rte.z;
   const uint32_t fr0 = (uint32_t)__builtin_amdgcn_readlane((int)frow, 0);
   float4 pv[2];
   auto request_chunk = [&](uint32_t c) {
@@ -238,8 +254,9 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
           d[2] = pi8_digits((int32_t)(v.z * ra.xs[4 * g + 2]));
           d[3] = pi8_digits((int32_t)(v.w * ra.xs[4 * g + 3]));
           pi8_planes(d, o);
+          // (the run-time slots' quad: no feature digits -- the coefficient rows carry other data in those words)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = o[p];
+          for (int p = 0; p < 4; ++p) sXd[wave][j][8 * p + g] = g == RT_QUAD ? 0u : o[p];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
