@@ -203,21 +203,6 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   float feat = 0.0f;
   if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t_first > 0)
     feat = Xf[((size_t)((t_first - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
-  // What a chunk's matrix-core section needs from global memory first -- its first subtile's row as floats (two slot quads
-  // per lane: lane = (day, two slot groups)) -- is requested ONE CHUNK AHEAD, in front of the day loop of the chunk
-  // before: the 16-day loop (~3 us of issue) covers the latency of these loads (rows of 16 different day slices:
-  // Infinity-Cache hits at best). Without that a wave's chunk was a chain load -> convert -> LDS -> MFMA -> day loop with
-  // the load exposed every time, and the kernel's time did not follow its instruction count
-  // (profiles/r06/ab_digit_table.log, ab_rollout_subtiles.log).
-  const uint32_t fr0 = (uint32_t)__builtin_amdgcn_readlane((int)frow, 0);
-  float4 pv[2];
-  auto request_chunk = [&](uint32_t c) {
-    const int j = lane >> 2, g0 = (lane & 3) * 2;
-    const float4 *xp = a.tb.X + ((size_t)min(c + (uint32_t)j, (uint32_t)a.tb.T - 1u) * rows_per_day + fr0) * (ROWF / 4);
-    pv[0] = xp[g0];
-    pv[1] = xp[g0 + 1];
-  };
-  if (total > 0) request_chunk(t_first);
   for (uint32_t c0 = t_first; total > 0; c0 += 16) {
     // ---- what the day loop reads of the float rows themselves -- the gate flag (slot 30) and the threshold policy's
     // feature --: lane (q, c16) fetches day c0 + c16 of ITS subtile's row (the subtile's envs share the row); requested
@@ -239,15 +224,16 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // (the previous subtile's B operands have been read)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // feature digits of days c0 .. c0 + 15 of that row: lane = (day, two slot groups); the first subtile's row was
-        // requested a chunk ahead, a further row of the wave (45 % of the waves hold two) is fetched here
+        // feature digits of days c0 .. c0 + 15 of that row: lane = (day, two slot groups). (Requesting the first row a
+        // chunk ahead, in front of the previous chunk's day loop, was measured: 516 / 498 us against 480 / 468 without --
+        // its 8 registers cost more than the hidden latency gains; profiles/r06/ab_rollout_subtiles.log)
         const int j = lane >> 2, g0 = (lane & 3) * 2;
         const uint32_t day = min(c0 + (uint32_t)j, (uint32_t)a.tb.T - 1u);
         const float4 *xp = a.tb.X + ((size_t)day * rows_per_day + fr) * (ROWF / 4);
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
           const int g = g0 + gg;
-          const float4 v = m == 0 ? pv[gg] : xp[g];
+          const float4 v = xp[g];
           uint32_t d[4], o[4];
           d[0] = pi8_digits((int32_t)(v.x * ra.xs[4 * g]));
           d[1] = pi8_digits((int32_t)(v.y * ra.xs[4 * g + 1]));
@@ -301,12 +287,6 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ)
     const int chunk = min(16, total);
-    // the next chunk's rows, in flight through this chunk's day loop. Scheduling barriers on both sides: the memory counter
-    // is in-order, so a wait for ANY later load -- the coefficients above, were they issued behind these -- would also
-    // wait for these; and hoisted above the fence they would be waited for right there
-    __builtin_amdgcn_sched_barrier(0);
-    if (total > chunk) request_chunk(c0 + 16);
-    __builtin_amdgcn_sched_barrier(0);
     for (int dd = 0; dd < chunk; ++dd, ++tu) {
       const float today = sDay[wave][q][dd][1], gate = sDay[wave][q][dd][0];
       const int32_t act = policy_action(kind, a.pol, pstream, tu, budget - (int32_t)used,
