@@ -985,6 +985,77 @@ def test_rollout_kernels_per_day_rewards(dev, kernel):
     B.close()
 
 
+def test_matrix_core_rollout_exact_path_and_slot27_rows(dev):
+    """k_rollout_mfma's per-lane EXACT path (plain fp64 dot products, a rolled loop since round 6) next to its fixed-point
+    path in the same waves: a third of the coefficient columns get a coefficient pair far outside the fixed-point range
+    (heat_qi +30, bias -15: logit shifts of -15 .. +15), another third a coefficient on the agent's 14-day count (slot 27:
+    `alert_2wks`, the appended observation key of env.py:191 -- none in the reference's weights, honoured if a weights file
+    has one), the rest stay as they are. The row's scale, its exact flag and its run-time coefficients travel in the
+    run-time-slot words of the int8 digit rows (k_rm_wq): every DAY against step() on a twin batch and -- the envs without a
+    slot-27 coefficient, which the oracle (like the reference's weights) does not know -- against the oracle."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd = synth.make_synth("linear", n_fips=24, years=[2006, 2007], n_samples=5, n_days=40, seed=29, extra_confounder_fips=3)
+    S = len(sd.fips_list)
+    big, a2w = np.arange(S) % 3 == 0, np.arange(S) % 3 == 1
+    rng = np.random.default_rng(3)
+    sd.weights["baseline_heat_qi"] = sd.weights["baseline_heat_qi"] + np.where(big, 30.0, 0.0).astype(np.float32)[None, None, :]
+    sd.weights["baseline_bias"] = sd.weights["baseline_bias"] - np.where(big, 15.0, 0.0).astype(np.float32)[None, None, :]
+    sd.weights["effectiveness_heat_qi"] = sd.weights["effectiveness_heat_qi"] + np.where(big, 24.0, 0.0).astype(np.float32)[None, None, :]
+    sd.weights["effectiveness_bias"] = sd.weights["effectiveness_bias"] - np.where(big, 12.0, 0.0).astype(np.float32)[None, None, :]
+    shape = sd.weights["baseline_bias"].shape
+    for head in ("baseline", "effectiveness"):
+        sd.weights[f"{head}_alert_2wks"] = (rng.normal(0, 0.05, shape) * a2w[None, None, :]).astype(np.float32)
+    ct = tables.compile_from_synth(sd)
+    W = np.asarray(ct.W).reshape(S, ct.n_samples, 2, 32)
+    assert (W[a2w][..., 27] != 0).any() and (W[~a2w][..., 27] == 0).all() and float(np.abs(W[big][..., :24]).max()) > 20
+    for head in ("baseline", "effectiveness"):  # the oracle's weights: without the key no reference weights file has
+        del sd.weights[f"{head}_alert_2wks"]
+    V = O.VectorOracle(O.RefData.from_synth(sd), sd.fips_weather, sd.years)
+    n, gid0 = 2000 + 11, 99
+    kw = dict(tables=ct, device=dev, autoreset="disabled", env_gid0=gid0)
+    A = HeatAlertVecEnv(n, rollout_mfma=True, **kw)
+    B = HeatAlertVecEnv(n, **kw)
+    A.reset(seed=5, options={"budget": 12})
+    B.reset(seed=5, options={"budget": 12})
+    st = _oracle_for_env(A, V)
+    cols = st["coef_col"]
+    assert big[cols].any() and a2w[cols].any() and (~big & ~a2w)[cols].any()
+    known = ~a2w[cols]  # envs whose reward the oracle can state
+    pol = dict(kind="bernoulli", p=0.4, seed=8)
+    worst = worst_step = 0.0
+    for t in range(ct.T):
+        out = A.rollout(pol, n_steps=1, alert_mask=True)
+        assert A.last_rollout_kernel == "k_rollout_mfma", (t, A.last_rollout_kernel)
+        att = out["attempt_days"][:, t].to(torch.int32)
+        _, r_b, _, _, _ = B.step(att)
+        _, r_o, done_o, actual_o = V.step(att.cpu().numpy())
+        r_a = out["return"].cpu().numpy().astype(np.float64)
+        worst = max(worst, float(np.abs(r_a - r_o)[known].max()))
+        worst_step = max(worst_step, float(np.abs(r_a - r_b.cpu().numpy()).max()))
+        np.testing.assert_array_equal(out["alerts"].cpu().numpy(), actual_o)
+    assert worst <= REWARD_TOL and worst_step <= 2e-6, (worst, worst_step)
+    assert float(np.abs(r_b.cpu().numpy() - r_o)[~known].max()) > 1e-4  # (the slot-27 coefficients do act)
+    # ... and a whole episode in one launch (several 16-day chunks; every subtile fill)
+    for e in (A, B):
+        e.reset(seed=6, options={"budget": 12})
+    _oracle_for_env(A, V)
+    pol2 = dict(kind="threshold", feature="heat_qi", threshold=0.6, require_budget=True)
+    oa = A.rollout(pol2)
+    ret_o, al_o, _, _ = O.oracle_rollout(V, dict(pol2, col=ct.columns.index("heat_qi")), ct.T, None)
+    np.testing.assert_array_equal(oa["alerts"].cpu().numpy(), al_o)
+    np.testing.assert_allclose(oa["return"].cpu().numpy()[known], ret_o[known], rtol=RETURN_RTOL, atol=RETURN_ATOL)
+    B.rollout_mfma = False  # (B has not rolled out yet: no tile list exists, the order alone serves k_rollout64)
+    ob = B.rollout(pol2)  # k_rollout64: the vector kernel's plain dot products, slot 27 included
+    assert B.last_rollout_kernel == "k_rollout64"
+    torch.testing.assert_close(oa["return"], ob["return"], rtol=3e-6, atol=3e-5)
+    assert torch.equal(oa["alerts"], ob["alerts"])
+    assert A.check_status() == 0 and B.check_status() == 0
+    print(f"k_rollout_mfma with exact-path and slot-27 rows: per-day |reward - oracle| <= {worst:.2e}, vs step() <= {worst_step:.2e}")
+    A.close()
+    B.close()
+
+
 def test_rollout_visiting_order_does_not_change_results(dev):
     """w2a_rollout_order only changes which lane serves which env (envs that share a feature row sit together) and
     lets the lane = env form of the day loop run: integer outputs and state are identical to the index-order rollout
