@@ -11,18 +11,19 @@
 // a GEMM with M = envs of the feature row, N = days, K = 32 slots. Only alert_lag1, alert_streak and remaining_budget
 // (slots 24..26) follow the agent's actions; they are added per day in fp64. The GEMM runs on v_mfma_i32_16x16x64_i8 with
 // the exact fixed-point digits of w2a_posterior_i8.hip.h -- here the ENV rows carry the coefficient digits (A operands
-// P = (W0 | W1), Q = (W2 | W3), gathered once per launch from a digit table of W built once per handle, run-time slots
-// zeroed so that they do not inflate the row's scale) and the DAY columns carry the feature digits
-// (B_m = (X_m | X_{m-1}), converted per 16-day chunk from the float32 rows of the (county, year)). Same six MFMAs per
-// 16 x 16 tile, same a-priori bound |dz| <= 1.5 * 2^(ew - 23.4); coefficient rows outside the fixed-point range
-// (rowflag) make their env compute the plain fp64 dot product per day instead (per lane, rare).
+// P = (W0 | W1), Q = (W2 | W3), gathered once per launch from a digit table of W built once per handle; the run-time slots
+// carry no digits -- they do not inflate the row's scale, and their words hold the row's scale, exact flag and run-time
+// coefficients instead, see k_rm_wq) and the DAY columns carry the feature digits (B_m = (X_m | X_{m-1}), converted per
+// 16-day chunk from the float32 rows of the (county, year)). Same six MFMAs per 16 x 16 tile, same a-priori bound
+// |dz| <= 1.5 * 2^(ew - 23.4); coefficient rows outside the fixed-point range (a negative scale) make their env compute the
+// plain fp64 dot product per day instead (per lane, rare).
 //
 // One wave = FOUR SUBTILES of <= 16 envs, each of ONE feature row (subtile list of w2a_rollout_mfma_prepare: the envs of a
 // (county, year) in runs of 16, the last one partial) = the four 16-row tiles of the GEMM's M dimension; lock step required
 // (every env on the same day: the handle's bookkeeping, else k_rollout64 serves the call). Until round 6 a wave was one
 // tile of <= 64 envs of one feature row: at 1 M envs over 8 206 (county, year) rows -- 128 envs per row on average -- that
 // left a third of the lanes idle (24 592 waves for 16 384 x 64 envs) in a kernel whose cost is per wave-day; padding to
-// 16 instead of 64 wastes 6 %. Per 16-day chunk and subtile: the feature digits of its row's 16 days -> the wave's LDS
+// 16 instead of 64 wastes 11 % (18 440 waves). Per 16-day chunk and subtile: the feature digits of its row's 16 days -> the wave's LDS
 // (128 (day, slot group) conversions; skipped when the subtile continues the previous one's row, which is the common
 // case: a row's ~8 subtiles sit in consecutive waves), B operands from there, 2 heads x 6 MFMAs, the int32 sums -> f32
 // logit parts -> LDS [env][day][head]; then 16 days of k_rollout64's day loop with 3 + 3 fp64 FMAs in place of 30 + 30.
