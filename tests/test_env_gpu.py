@@ -1039,7 +1039,7 @@ def test_matrix_core_rollout_exact_path_and_slot27_rows(dev):
     # ... and a whole episode in one launch (several 16-day chunks; every subtile fill)
     for e in (A, B):
         e.reset(seed=6, options={"budget": 12})
-    _oracle_for_env(A, V)
+    known = ~a2w[_oracle_for_env(A, V)["coef_col"]]
     pol2 = dict(kind="threshold", feature="heat_qi", threshold=0.6, require_budget=True)
     oa = A.rollout(pol2)
     ret_o, al_o, _, _ = O.oracle_rollout(V, dict(pol2, col=ct.columns.index("heat_qi")), ct.T, None)
