@@ -219,20 +219,21 @@ int w2a_step(w2a_env *env, const void *actions, int action_dtype, float *obs, fl
              float *last_return, int flags, void *stream);
 
 /* episode_order="sorted" (no reference counterpart; opt-in): after a reset, relabel the envs so that env
- * indices follow the coefficient row. The multiset of episodes is unchanged -- only which env index holds
- * which episode -- but neighbouring envs now share table lines, which the step kernel's gathers turn into
- * L2 hits. The whole per-env record moves (episode tuple, budget, sticky budget, episode number).
+ * indices follow the coefficient row (column, draw); envs of one row keep their order (a stable sort). The
+ * multiset of episodes is unchanged -- only which env index holds which episode -- but neighbouring envs now
+ * share table lines, which the step kernel's gathers turn into L2 hits. The whole per-env record moves
+ * (episode tuple, budget, sticky budget, episode number).
  * workspace: caller-owned, w2a_sort_workspace_bytes(num_envs) bytes, 256-B aligned. */
 size_t w2a_sort_workspace_bytes(int64_t num_envs);
 int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, void *stream);
 /* The same relabelling fused into the whole-batch device-RNG reset that precedes it (what episode_order="sorted" does once
  * per episode): w2a_reset_device_rng + w2a_sort_episodes + w2a_observe in three launches and no moved record. Pass 1 draws
- * every env's next episode and keeps only its sort key -- (coefficient row, feature row) as one 32-bit word -- with the env's
- * sticky budget and episode number; a stable radix sort of (key, env index); pass 2 is k_reset with "index e receives the
+ * every env's next episode and keeps only its sort key -- the coefficient row (column, draw) -- with the env's sticky
+ * budget and episode number; a stable radix sort of (key, env index); pass 2 is k_reset with "index e receives the
  * episode env src[e] draws" (same global id, sticky budget and episode number as that env's own draw: the result is bit
  * for bit that of the three calls above) and writes state and first observations (obs nullable) in place.
  * Arguments as w2a_reset_device_rng without a mask; workspace as w2a_sort_episodes. Returns 1 (nothing done) when the key
- * does not fit 32 bits (S * n_samples * S_w * Y > 2^32): the caller runs the three calls instead. */
+ * does not fit 32 bits (S * n_samples > 2^32): the caller runs the three calls instead. */
 int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, int augment, int32_t budget_kw,
                                 int sample_budget_mode, int sticky, int restart_episodes, float *obs, void *workspace,
                                 size_t workspace_bytes, void *stream);

@@ -217,10 +217,9 @@ class HandleModel:
         self.pending_reset = False
 
     def _relabel(self):
-        """w2a_sort_episodes: stable sort of the whole per-env record by (coefficient row, feature row)."""
+        """w2a_sort_episodes: stable sort of the whole per-env record by coefficient row (column, draw)."""
         V = self.V
-        key = (((V.coef_col.astype(np.uint64) << np.uint64(12)) | V.sample.astype(np.uint64)) << np.uint64(32)) | \
-            (V.county_w * self.ct.Y + V.year_i).astype(np.uint64)
+        key = (V.coef_col.astype(np.uint64) << np.uint64(12)) | V.sample.astype(np.uint64)
         p = np.argsort(key, kind="stable")
         for k in ("county_w", "year_i", "coef_col", "sample", "budget", "n_days") + _V_FIELDS:
             setattr(V, k, getattr(V, k)[p])

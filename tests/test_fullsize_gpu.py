@@ -400,8 +400,10 @@ def test_full_size_sorted_episode_order_vs_oracle(dev):
     ka, kb = packed(iid), packed(srt)
     assert torch.equal(torch.sort(ka).values, torch.sort(kb).values)  # same multiset of episode records
     sb = srt.state()
-    row = ((sb["coef_col"].long() << 12 | sb["sample"].long()) << 32) | (sb["county_w"].long() * ct.Y + sb["year_i"].long())
+    row = sb["coef_col"].long() << 12 | sb["sample"].long()
     assert bool((row[1:] >= row[:-1]).all()) and not torch.equal(ka, kb)
+    sa = iid.state()  # envs of one coefficient row keep the iid order's order: the permutation is THE stable sort
+    assert torch.equal(kb, ka[torch.sort(sa["coef_col"].long() << 12 | sa["sample"].long(), stable=True).indices])
     iid.close()
     idx = _sample(n, 16384)
     it = torch.as_tensor(idx, device=dev)
@@ -424,7 +426,7 @@ def test_full_size_sorted_episode_order_vs_oracle(dev):
     # the lock-step autoreset relabelled the next episode too
     s3 = srt.state()
     assert bool((s3["episode_no"] == 1).all()) and bool((s3["t"] == 0).all())
-    row = ((s3["coef_col"].long() << 12 | s3["sample"].long()) << 32) | (s3["county_w"].long() * ct.Y + s3["year_i"].long())
+    row = s3["coef_col"].long() << 12 | s3["sample"].long()
     assert bool((row[1:] >= row[:-1]).all())
     assert srt.check_status() == 0
     srt.close()

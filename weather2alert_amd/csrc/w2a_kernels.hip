@@ -375,11 +375,20 @@ static size_t cub_sort_bytes(int64_t n) {
   return b;
 }
 
-// The fused sorted reset's radix sort goes to rocprim directly with the merge-sort limit at 0: the library's default sends
-// batches of up to 1 048 576 items -- exactly BASELINE's 1 M envs -- to a merge sort (block sort + 10 merge passes, 150 us,
-// whatever the bit range: profiles/r06/kernel_stats_configs2_sorted.csv before this change) instead of the onesweep radix
-// sort, which needs 4 passes for the 28 key bits. Both are stable.
-using Sort32Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+// The 32-bit (key, index) radix sorts go to rocprim directly, on its onesweep algorithm with a configuration of their own
+// (tools/exp_sort_configs.hip, profiles/r06/exp_sort_configs.log; 1 048 576 pairs, 17 key bits):
+//   * merge-sort limit 0: the library's default sends batches of up to 1 048 576 items -- exactly BASELINE's 1 M envs -- to
+//     a merge sort (block sort + 10 merge passes, 150 us whatever the bit range);
+//   * 9 bits per pass instead of 8: the 17 bits of a coefficient row are two passes instead of three;
+//   * 1024 threads x 8 items per block: 128 blocks per pass. Smaller blocks fill more CUs and are SLOWER (256 x 8: 104 us
+//     against 53): a pass is bound by its chain of decoupled look-backs, one link per block, not by bandwidth.
+// 53 us against the library's 105 (17 bits) / 138 (the 28 bits of round 6's first key, which had the feature row as its
+// minor part). Stable, like every LSD radix sort.
+using Sort32Config =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
+                                                                   rocprim::block_radix_rank_algorithm::match>,
+                               0>;
 static hipError_t sort32_pairs(void *tmp, size_t &bytes, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in,
                                uint32_t *v_out, size_t n, unsigned end_bit, hipStream_t s) {
   return rocprim::radix_sort_pairs<Sort32Config>(tmp, bytes, k_in, k_out, v_in, v_out, n, 0u, end_bit, s);
@@ -427,7 +436,14 @@ int w2a_sort_episodes(w2a_env *env, void *workspace, size_t workspace_bytes, voi
   }
   hipLaunchKernelGGL(k_sort_keys, dim3(blocks), dim3(256), 0, s, env->st.cold, k_in, i_in, env->n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
+  // the high word only -- env indices follow the coefficient row; envs of one row keep their order (stable): the same
+  // permutation as w2a_reset_device_rng_sorted's. The bit range stops at the packed word's highest used bit and never at
+  // 64: for up to 1 M items rocprim merge-sorts with a comparator whose mask is built as (T(1) << end_bit) - 1, which for
+  // end_bit = 64 is a shift by the type's width -- it then compares the LOW word (seen on gfx950: the batch came back in
+  // feature-row order)
+  int col_bits = 1;
+  while (col_bits < 31 - SAMPLE_BITS && ((uint32_t)(env->tb.S - 1) >> col_bits)) ++col_bits;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, k_in, k_out, i_in, i_out, (int)n, 32, 32 + SAMPLE_BITS + col_bits, s));
   StateArrays tmp;
   tmp.cold = cold_t; tmp.hot3 = hot_t; tmp.stepc = stepc_t;
   hipLaunchKernelGGL(k_permute_state, dim3(blocks), dim3(256), 0, s, env->st, i_out, tmp, env->n);
@@ -450,9 +466,9 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
   memset(&a, 0, sizeof(a));
   const int rc = fill_cfg(env, a.rc, seed, location, augment, budget_kw, sample_budget_mode, sticky);
   if (rc) return rc;
-  // (coefficient row, feature row) as one 32-bit key: 167 M values on the reference's tables. Larger tables take the
-  // general path (w2a_reset_device_rng + w2a_sort_episodes + w2a_observe): the caller is told with return value 1
-  const uint64_t key_space = (uint64_t)env->tb.S * env->tb.n_samples * ((uint64_t)env->tb.S_w * env->tb.Y);
+  // the coefficient row as a 32-bit key (74 600 values on the reference's tables). More than 2^32 rows take the general
+  // path (w2a_reset_device_rng + w2a_sort_episodes + w2a_observe): the caller is told with return value 1
+  const uint64_t key_space = (uint64_t)env->tb.S * (uint64_t)env->tb.n_samples;
   if (key_space > 0xFFFFFFFFull) return 1;
   REFUSE_WHILE_CAPTURING("w2a_reset_device_rng_sorted", stream);
   int end_bit = 1;
@@ -490,7 +506,7 @@ int w2a_reset_device_rng_sorted(w2a_env *env, uint64_t seed, int32_t location, i
   return W2A_OK;
 }
 
-static size_t cub_group_bytes(int64_t n) { return cub_sort32_bytes(n); }  // the same onesweep sort (10 key bits: 2 passes)
+static size_t cub_group_bytes(int64_t n) { return cub_sort32_bytes(n); }  // the same onesweep sort (10 key bits: 2 passes of 9 + 1)
 
 static size_t wd_bytes(int32_t S, int32_t n_samples) { return align256((size_t)S * n_samples * 2 * ROWF * sizeof(double)); }
 // tiles of the posterior-mean kernel: at most one partial tile per column on top of n / PMV_THREADS full ones

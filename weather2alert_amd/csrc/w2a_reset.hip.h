@@ -103,9 +103,10 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const ResetArgs a) {
   if (a.obs) store_obs_tile(a.obs, s_tile[wave], wave_env0, a.n, a.tb.n_obs, lane, grp, x, so, sel);
 }
 
-// w2a_reset_device_rng_sorted, first pass: the key of the episode every env is about to draw -- coefficient row (column,
-// draw) major, feature row minor, as ONE 32-bit word -- with the env's index, and what the second pass needs of the env's
-// old record once other indices' records have been overwritten: its sticky budget and the new episode's number.
+// w2a_reset_device_rng_sorted, first pass: the key of the episode every env is about to draw -- its coefficient row
+// (column, draw): 17 bits on the reference's tables, two 9-bit passes of the radix sort -- with the env's index, and what
+// the second pass needs of the env's old record once other indices' records have been overwritten: its sticky budget and
+// the new episode's number. (Envs of one coefficient row keep their index order: the sort is stable.)
 __global__ void k_reset_keys(DevTables tb, ResetCfg rc, StateArrays st, int64_t n, int64_t gid0, int32_t restart,
                              uint32_t *keys, uint32_t *idx, uint2 *zw) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,7 +114,7 @@ __global__ void k_reset_keys(DevTables tb, ResetCfg rc, StateArrays st, int64_t 
   const uint4 cold = st.cold[i];
   const uint32_t epno = restart ? 0u : cold.w + 1u;
   const Episode ep = draw_episode(tb, rc, (uint64_t)(gid0 + i), epno, (int32_t)cold.z);
-  keys[i] = (W_COL(ep.ep_w) * (uint32_t)tb.n_samples + W_SAMPLE(ep.ep_w)) * (uint32_t)(tb.S_w * tb.Y) + ep.ep_row;
+  keys[i] = W_COL(ep.ep_w) * (uint32_t)tb.n_samples + W_SAMPLE(ep.ep_w);
   idx[i] = (uint32_t)i;
   zw[i] = make_uint2(cold.z, epno);
 }

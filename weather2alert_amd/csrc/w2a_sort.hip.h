@@ -10,7 +10,7 @@ __global__ void k_sort_keys(const uint4 *cold, uint64_t *keys, uint32_t *idx, in
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint4 c = cold[i];
-  keys[i] = ((uint64_t)c.y << 32) | c.x;  // coefficient row (column, draw) major, weather row minor
+  keys[i] = ((uint64_t)c.y << 32) | c.x;  // coefficient row (column, draw) in the high word: the bits that are sorted
   idx[i] = (uint32_t)i;
 }
 __global__ void k_permute_state(StateArrays src, const uint32_t *idx, StateArrays dst, int64_t n) {

@@ -30,9 +30,9 @@ class KernelOptions:
     # env's own batch after the first reset and keeps the fastest -- a per-process choice unless the env is given
     # pm_sync_group=, which broadcasts the group's first rank's choice: a collective inside the first reset())
     pm_kernel: Literal["auto", "vector", "matrix", "matrix_i8"] = "matrix_i8"
-    # episode_order="sorted": "fused" = w2a_reset_device_rng_sorted (draw keys, one stable 32-bit radix sort, k_reset that
-    # writes every index the episode of its source env: no record is moved); "relabel" = round 5's sequence
-    # w2a_reset_device_rng + w2a_sort_episodes (64-bit keys, state permutation, three copies) + w2a_observe. Bit-identical.
+    # episode_order="sorted": "fused" = w2a_reset_device_rng_sorted (draw keys, one stable radix sort of the coefficient
+    # row, k_reset that writes every index the episode of its source env: no record is moved); "relabel" = round 5's
+    # sequence w2a_reset_device_rng + w2a_sort_episodes (state permutation, three copies) + w2a_observe. Bit-identical.
     sorted_reset: Literal["fused", "relabel"] = "fused"
 
     def __post_init__(self):
