@@ -373,6 +373,36 @@ def test_full_size_posterior_mean_rollout_vs_oracle(dev, pm_kernel):
         V.reward_mode = "sampled"
 
 
+def test_full_size_sorted_reset_paths_agree(dev):
+    """episode_order='sorted' on BASELINE's tables at 1 048 576 envs and just above: the fused reset (32-bit keys, rocprim
+    onesweep with 9-bit passes) and the three-call sequence (64-bit keys through hipcub: a merge sort up to 1 048 576
+    items, a radix sort above -- the two library paths take the bit range differently, see w2a_sort_episodes) give the same
+    batch, which is THE stable sort of the iid batch by coefficient row; through a second, sticky episode as well."""
+    from weather2alert_amd import HeatAlertVecEnv
+
+    sd, ct, dt, V = full_tables("linear", dev)
+    kw = dict(tables=dt, device=dev, similar_climate_counties=True)
+    opts = {"sample_budget": True, "sample_budget_type": "centered"}
+    for n in (1 << 20, (1 << 20) + 64 * 3 + 5):
+        iid = HeatAlertVecEnv(n, autoreset="disabled", **kw)
+        fused = HeatAlertVecEnv(n, episode_order="sorted", sorted_reset="fused", **kw)
+        relab = HeatAlertVecEnv(n, episode_order="sorted", sorted_reset="relabel", **kw)
+        for episode in range(2):
+            for e in (iid, fused, relab):
+                e.reset(seed=11 + episode, options=opts)
+            si, sf, sr = iid.state(), fused.state(), relab.state()
+            for k in sf:
+                assert torch.equal(sf[k], sr[k]), (n, episode, k)
+            if episode == 0:  # (afterwards a sticky budget follows its RECORD, which the relabelling has moved to another index)
+                perm = torch.sort(si["coef_col"].long() << 12 | si["sample"].long(), stable=True).indices
+                for k in ("county_w", "year_i", "coef_col", "sample", "budget", "sticky_budget"):
+                    assert torch.equal(sf[k], si[k][perm]), (n, episode, k)
+            assert torch.equal(fused._obs, relab._obs)
+        assert fused.check_status() == 0 and relab.check_status() == 0
+        for e in (iid, fused, relab):
+            e.close()
+
+
 def test_full_size_sorted_episode_order_vs_oracle(dev):
     """episode_order='sorted' at 1 048 576 envs (S = 746, augmented): the relabelled batch holds the same multiset of
     episode records as the iid order for the same seed, env indices follow the coefficient rows, and one whole
