@@ -934,6 +934,11 @@ def test_on_device_policy_rollout_matches_policy_loop(dev, kind):
     np.testing.assert_array_equal(s2["used"], V.used)
     np.testing.assert_array_equal(s2["streak"], V.streak)
     np.testing.assert_array_equal(s2["t"], V.t)
+    # (the matrix-core kernel carries the budget as what remains and, for require_budget policies, derives "at budget" after
+    # its day loop instead of comparing every day)
+    np.testing.assert_array_equal(s2["at_budget"], V.at_budget.astype(np.int32))
+    np.testing.assert_array_equal(s2["last_actual"], V.last_actual)
+    np.testing.assert_array_equal(s2["budget"] - s2["used"], V.budget - V.used)
     stats = HeatAlertVecEnv.episode_stats(out)
     assert abs(stats["mean_alerts"] - al_o.mean()) < 1e-9
     np.testing.assert_array_equal(stats["alert_day_hist"].numpy(), days_o.sum(0))
@@ -1134,6 +1139,12 @@ def test_matrix_core_rollout_matches_vector_rollout_and_oracle(dev, kind):
         np.testing.assert_array_equal(oa["alert_days"].cpu().numpy(), days_o)
         torch.testing.assert_close(oa["return"], ob["return"], rtol=3e-6, atol=3e-5)
         np.testing.assert_allclose(oa["return"].cpu().numpy(), ret_o, rtol=RETURN_RTOL, atol=RETURN_ATOL)
+        if steps:  # (a rollout to the end is followed by the lock-step autoreset: nothing of the old episode is left to compare)
+            sa, sb = A.state(), B.state()
+            for k in ("t", "used", "streak", "last_actual", "at_budget", "hist14", "budget", "finished"):
+                assert torch.equal(sa[k], sb[k]), (steps, k)  # (the matrix-core kernel derives some of these after its day loop)
+            np.testing.assert_array_equal(sa["at_budget"].cpu().numpy(), V.at_budget.astype(np.int32))
+            np.testing.assert_array_equal(sa["used"].cpu().numpy(), V.used)
         return oa
 
     check(21)   # starts on day 0, ends inside a 16-day chunk

@@ -179,12 +179,18 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   }
   const bool exact = sc_b < 0.0f || sc_e < 0.0f;  // this env's coefficient row is outside the fixed-point range (or uses slot 27)
   const bool any_exact = __any(exact) != 0;       // wave-uniform: the common case never enters the exact path's control flow
-  sc_b = fabsf(sc_b); sc_e = fabsf(sc_e);
+  // The day loop works on -log2(e) x logit, what v_exp_f32 wants (as k_posterior_mean_i8 does): the factor rides in the row
+  // scales (a power of two times the constant: one rounding, where the plain form rounds the product with the constant)
+  // and in the fp64 run-time coefficients, instead of two multiplies per env-day
+  constexpr float NL2E = -1.44269504088896340736f;
+  constexpr double NL2E_D = -1.44269504088896340736;
+  sc_b = fabsf(sc_b) * NL2E; sc_e = fabsf(sc_e) * NL2E;
+  wl_b *= NL2E_D; ws_b *= NL2E_D; wr_b *= NL2E_D; wl_e *= NL2E_D; ws_e *= NL2E_D; wr_e *= NL2E_D;
   const float *Xf = reinterpret_cast<const float *>(a.tb.X);
   const uint64_t pstream = rng_stream(a.pol.seed ^ 0xA5A5A5A55A5A5A5Aull, (uint64_t)(a.gid0 + e), episode_no);
   constexpr int32_t kind = KIND;
   float ret = 0.0f;
-  int32_t alerts = 0, over = 0;
+  int32_t over = 0;
   uint32_t mask_word = 0, att_word = 0;
   float snap = 0.0f;
   bool snapped = false;
@@ -200,19 +206,22 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
   int total = fin_u ? 0 : min(a.n_steps, (int)(nd_u - t_first));  // days this call runs
   const bool ends = !fin_u && total == (int)(nd_u - t_first);     // ... the terminal one among them
   uint32_t tu = t_first;                                          // today
-  // threshold policy: the lagging observation (row of day t - 1, Q6) is carried from day to day; obs_lag = 0 reads today's
-  float feat = 0.0f;
-  if (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag && t_first > 0)
-    feat = Xf[((size_t)((t_first - 1) * rows_per_day + frow)) * ROWF + a.pol_slot];
+  // threshold policy: what the agent sees on day d is the row of day d - 1 (the lagging observation, Q6; day 0 and
+  // obs_lag = 0: today's). The chunk's per-day LDS entries hold THAT row's feature, so the day loop carries nothing over
+  const uint32_t lag = (kind == W2A_POLICY_THRESHOLD && a.pol.obs_lag) ? 1u : 0u;  // wave-uniform
+  const bool req = a.pol.require_budget != 0;                                       // wave-uniform
+  const uint32_t used0 = used;
+  int32_t rem = budget - (int32_t)used;  // what remains of the budget (negative for a negative budget: never "at budget")
+  const bool ran = total > 0;
   for (uint32_t c0 = t_first; total > 0; c0 += 16) {
     // ---- what the day loop reads of the float rows themselves -- the gate flag (slot 30) and the threshold policy's
     // feature --: lane (q, c16) fetches day c0 + c16 of ITS subtile's row (the subtile's envs share the row); requested
     // here, stored to LDS behind the matrix-core section, whose work covers their latency
     float pd_gate, pd_feat = 0.0f;
     {
-      const float *xr = Xf + ((size_t)min(c0 + (uint32_t)c16, (uint32_t)a.tb.T - 1u) * rows_per_day + frow) * ROWF;
-      pd_gate = xr[4 * GATE_QUAD + 2];
-      if (kind == W2A_POLICY_THRESHOLD) pd_feat = xr[a.pol_slot];
+      const uint32_t d = min(c0 + (uint32_t)c16, (uint32_t)a.tb.T - 1u);
+      pd_gate = Xf[((size_t)d * rows_per_day + frow) * ROWF + 4 * GATE_QUAD + 2];
+      if (kind == W2A_POLICY_THRESHOLD) pd_feat = Xf[((size_t)(d - min(d, lag)) * rows_per_day + frow) * ROWF + a.pol_slot];
     }
     // ---- per subtile m (= 16-row tile of the GEMM): the B operands of its row's 16 days, then 2 heads x 6 MFMAs
     pi8_v4i B[4];
@@ -286,24 +295,34 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ)
+    // ---- the chunk's days, lane = env (k_rollout64's day loop with the table part of the logits taken from sZ).
+    // The body exists four times, chosen by two wave-uniform facts, so that none of them costs vector instructions per day:
+    //   REQ    the policy never alerts without budget (require_budget: act = 0 when nothing remains). Then an attempt at
+    //          budget cannot happen: actual = act, no "at budget" compare, no over-budget count (it stays 0 exactly);
+    //   FIRST  day 0 of the episode (only the first day of the first chunk can be): alert_lag1 = 0 whatever the action.
+    // The budget is carried as what REMAINS (remaining_budget is a reward feature; "at budget" is remaining == 0).
     const int chunk = min(16, total);
-    for (int dd = 0; dd < chunk; ++dd, ++tu) {
-      const float today = sDay[wave][q][dd][1], gate = sDay[wave][q][dd][0];
-      const int32_t act = policy_action(kind, a.pol, pstream, tu, budget - (int32_t)used,
-                                        (a.pol.obs_lag && tu > 0) ? feat : today);
-      const uint32_t atb_s = ((int32_t)used == budget) ? 1u : 0u;
-      const uint32_t actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
-      const uint32_t used2 = used + actual;
+    auto day = [&](auto req_c, auto first_c, const int dd) {
+      constexpr bool REQ = decltype(req_c)::value, FIRST = decltype(first_c)::value;
+      const float seen = sDay[wave][q][dd][1], gate = sDay[wave][q][dd][0];
+      const int32_t act = policy_action(kind, a.pol, pstream, tu, rem, seen);
+      uint32_t atb_s = 0u, actual = (uint32_t)act;
+      if (!REQ) {
+        atb_s = (rem == 0) ? 1u : 0u;
+        actual = (act == 1 && atb_s) ? 0u : (uint32_t)act;
+      }
+      const int32_t rem2 = rem - (int32_t)actual;
       const uint32_t hist2 = ((hist << 1) | actual) & 0x3FFFu;
-      const double f_lag = (double)(tu > 0 ? actual : 0u), f_streak = (double)streak;
-      const double f_rem = (double)(budget - (int32_t)used2);
+      const double f_lag = FIRST ? 0.0 : (double)actual, f_streak = (double)streak;
+      const double f_rem = (double)rem2;
       const float2 zt = *reinterpret_cast<const float2 *>(&sZ[wave][lane][dd * 2]);
       double zb = (double)(zt.x * sc_b), ze = (double)(zt.y * sc_e);
       if (any_exact) {   // wave-uniform; rare
         if (exact) {     // plain fp64 dot products for a coefficient row outside the fixed-point range (or with a slot-27 term)
           zb = 0.0; ze = 0.0;
-          const float4 *xr = a.tb.X + (size_t)(tu * rows_per_day + frow) * (ROWF / 4);
+          uint32_t tt = tu;
+          asm volatile("" : "+s"(tt));  // (keeps the row index of this rare path out of the day loop's induction variables)
+          const float4 *xr = a.tb.X + (size_t)(tt * rows_per_day + frow) * (ROWF / 4);
           const float4 *wr4 = reinterpret_cast<const float4 *>(Wf);
           // one quad of slots per trip, NOT unrolled: unrolled, this rare path held 16 float4 loads in flight and set the
           // register allocation of the whole kernel (the source of its spills until round 6)
@@ -319,17 +338,25 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
           const double f_a2w = (double)__popc(hist2);
           zb = fma(f_a2w, (double)Wf[27], zb);
           ze = fma(f_a2w, (double)Wf[ROWF + 27], ze);
+          zb *= NL2E_D; ze *= NL2E_D;
         }
       }
-      zb = fma(f_lag, wl_b, zb); zb = fma(f_streak, ws_b, zb); zb = fma(f_rem, wr_b, zb);
-      ze = fma(f_lag, wl_e, ze); ze = fma(f_streak, ws_e, ze); ze = fma(f_rem, wr_e, ze);
-      if (!(gate > 0.5f)) ze = -__builtin_inf();
-      const float r = reward_from_logits(zb, ze, actual);
+      if (!FIRST) { zb = fma(f_lag, wl_b, zb); ze = fma(f_lag, wl_e, ze); }
+      zb = fma(f_streak, ws_b, zb); zb = fma(f_rem, wr_b, zb);
+      ze = fma(f_streak, ws_e, ze); ze = fma(f_rem, wr_e, ze);
+      // env.py:211-221 on the negated, log2-scaled logits: sigmoid(z) = 1 / (1 + 2^(-log2(e) z)); a closed gate is
+      // logit -inf = +inf here: 2^inf = inf, 1 / inf = 0 exactly (reward_from_logits, w2a_common.hip.h, minus its two multiplies)
+      // The effectiveness counts on alert days only (eff x actual, actual in {0, 1}): "no alert" closes the gate as well,
+      // which gives the same 1 - 0 bit for bit and spares the env's action as a float.
+      float eb = (float)zb, ee = (float)ze;
+      if (!(gate > 0.5f && actual)) ee = __builtin_inff();
+      const float cb = -(1000.0f / 152.0f) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(eb));
+      const float eff = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ee));
+      const float r = fmaf(-cb, eff, cb);  // = c x base x (1 - eff), one rounding less
       const bool done = tu + 1 >= nd_u;  // wave-uniform: the last day this call runs, if it runs to the end
       ret += r;
       ret_total += r;
-      alerts += (int32_t)actual;
-      over += (act == 1 && atb_s) ? 1 : 0;
+      if (!REQ) over += (act == 1 && atb_s) ? 1 : 0;
       if (MASKS) {
         mask_word |= actual << (tu & 31u);
         att_word |= (uint32_t)(act == 1) << (tu & 31u);
@@ -343,9 +370,26 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
         }
         if ((done ? tu : tu + 1) + 2 == nd_u) { snap = ret_total; snapped = true; }
       }
-      used = used2; hist = hist2; last = actual; atb = atb_s;
-      if (!done) streak = actual ? streak + 1 : 0;  // (env.py:256-260: the terminal step leaves day and streak as they are)
-      feat = today;
+      rem = rem2; hist = hist2; last = actual;
+      if (!REQ) atb = atb_s;
+      {  // streak = actual ? streak + 1 : 0 as actual x streak + actual: one instruction (written as a select the compiler
+         // emits two); env.py:256-260: the terminal step leaves day and streak as they are
+        uint32_t s2;
+        asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(s2) : "v"(actual), "v"(streak));
+        streak = done ? streak : s2;
+      }
+      ++tu;
+    };
+    {
+      const std::true_type yes;
+      const std::false_type no;
+      int dd = 0;
+      if (tu == 0u) {
+        if (req) day(yes, yes, 0); else day(no, yes, 0);
+        dd = 1;
+      }
+      if (req) for (; dd < chunk; ++dd) day(yes, no, dd);
+      else for (; dd < chunk; ++dd) day(no, no, dd);
     }
     total -= chunk;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -353,11 +397,13 @@ __global__ __launch_bounds__(64 * RM_WAVES, RM_MIN_WAVES) void k_rollout_mfma(co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (!fin_u) { t = ends ? nd_u - 1u : tu; fin = ends; }
+  used = (uint32_t)(budget - rem);
+  if (req && ran) atb = (rem + (int32_t)last == 0) ? 1u : 0u;  // "at budget" as the last day's step found it (env.py:243)
   if (valid) {
     store_hot(a.st, e, make_uint4(pack_d0(t, used, streak, last, atb), pack_d1(hist, ndays, fin ? 1u : 0u),
                                   __float_as_uint(ret_total), (uint32_t)budget));
     if (a.ret_out) a.ret_out[e] = ret;
-    if (a.alerts_out) a.alerts_out[e] = alerts;
+    if (a.alerts_out) a.alerts_out[e] = (int32_t)(used - used0);  // every alert issued is one unit of budget used (env.py:246-250)
     if (a.attempts_over_budget) a.attempts_over_budget[e] = over;
     if (MASKS && a.ret_snapshot && snapped) a.ret_snapshot[e] = snap;
     if (fin && a.last_return && !D1_FIN(hot.y)) a.last_return[e] = ret_total;
