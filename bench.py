@@ -1152,6 +1152,21 @@ def main():
         if stepno % T == 0:  # lock step: every env just finished an episode
             gather_returns()
 
+    # Host housekeeping BEFORE the warm-up steps, so that nothing slow stands between them and the timed region: a
+    # collector pass over this process's heap takes tens of milliseconds, and a GPU left idle that long starts its next
+    # launches slowly -- 20 steps behind a gc.collect() cost 2.7 us per step more than 20 steps behind other steps
+    # (profiles/r06/exp_sync_latency.log: 37.5 against 34.8 us, wall; timing events inside the window cost nothing).
+    # Until round 6 the collect sat between the warm-up and the region: 3 of the ~4.5 us per step by which the driver's
+    # 20-step window read slower than a long run. The collector stays off from here to the end of the timed region.
+    import gc
+
+    gc.collect()
+    gc.disable()
+    # the first HIP event a process records creates the runtime's event pool (measured: 0.15 ms for that one call,
+    # 7 us afterwards, profiles/r03/exp_window_latency.log); the timing events below must not pay for it inside the region
+    for _ in range(2):
+        _w0, _w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _w0.record(); _w1.record(); _w1.synchronize(); _w0.elapsed_time(_w1)
     for _ in range(args.warmup):
         one_step()
     gather.wait()
@@ -1180,21 +1195,13 @@ def main():
             for i in range(args.graph):
                 env.step(pool[i & 15])
         torch.cuda.synchronize()
-    # the first HIP event a process records creates the runtime's event pool (measured: 0.15 ms for that one call,
-    # 7 us afterwards, profiles/r03/exp_window_latency.log); the timing events below must not pay for it inside the region
-    for _ in range(2):
-        _w0, _w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        _w0.record(); _w1.record(); _w1.synchronize(); _w0.elapsed_time(_w1)
-    import gc
-
     first_ev = []
 
     def timed_region(segments: bool):
         """EXACTLY args.steps steps between barrier + device synchronisation on both sides; (wall seconds on this rank,
         device milliseconds). segments: also record the per-episode HIP events of the headline's kernel timing."""
         nonlocal seg_on, stepno
-        gc.collect()
-        gc.disable()  # no collector pause inside the timed region (re-enabled right after it)
+        gc.disable()  # no collector pause inside the timed region (re-enabled right after it; the collect ran before the warm-up)
         wdist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
